@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Run in the build container only (the reference checkout does not travel):
+
+    python tests/golden/make_golden.py [/root/reference]
+
+It imports the reference's ``train/unet.py`` and ``main.py`` (CPU, fp32,
+torch seeds stated per fixture), runs them on small seeded inputs and stores
+inputs, weights and expected outputs/gradients as ``.npz`` files.  ``main.py``
+imports ``train/resnet18.py`` which needs ``segmentation_models_pytorch``
+(not installed): an EMPTY stub module is registered for that name so that
+``compute_loss`` / the step order become importable; ``PretrainedTemporalUNet``
+is never instantiated.
+
+Fixtures are data only: no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.modules.setdefault("segmentation_models_pytorch", types.ModuleType("segmentation_models_pytorch"))
+
+from train.unet import (ConvLSTMCell, ConvLSTM, DoubleConv, Down, Up, OutConv,  # noqa: E402
+                        SpatialAttention, TemporalUNetDualView, NPZSequenceDataset)
+import main as ref_main  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(t):
+    return t.detach().cpu().clone().numpy()   # clone: later in-place updates must not alias saved arrays
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(arrs)} arrays)")
+
+
+def sd_arrays(mod, prefix="p/"):
+    return {prefix + k: npy(v) for k, v in mod.state_dict().items()}
+
+
+# ---------------------------------------------------------------- 1. cell
+def gen_cell():
+    out = {}
+    for tag, (cin, hd, B, H, W, seed) in {
+        "a": (4, 8, 2, 16, 16, 100),
+        "b": (4, 5, 2, 7, 9, 101),        # hidden_dim not a multiple of anything, non-square
+    }.items():
+        torch.manual_seed(seed)
+        cell = ConvLSTMCell(cin, hd)
+        x = torch.randn(B, cin, H, W, requires_grad=True)
+        h0 = (0.5 * torch.randn(B, hd, H, W)).requires_grad_(True)
+        c0 = (0.5 * torch.randn(B, hd, H, W)).requires_grad_(True)
+        h1, (_, c1) = cell(x, (h0, c0))
+        (h1.sum() + c1.sum()).backward()
+        out.update({f"{tag}/weight": npy(cell.conv.weight), f"{tag}/bias": npy(cell.conv.bias),
+                    f"{tag}/x": npy(x), f"{tag}/h0": npy(h0), f"{tag}/c0": npy(c0),
+                    f"{tag}/h1": npy(h1), f"{tag}/c1": npy(c1),
+                    f"{tag}/gx": npy(x.grad), f"{tag}/gh0": npy(h0.grad), f"{tag}/gc0": npy(c0.grad),
+                    f"{tag}/gw": npy(cell.conv.weight.grad), f"{tag}/gb": npy(cell.conv.bias.grad)})
+        # state=None case
+        hn, (_, cn) = cell(x.detach())
+        out.update({f"{tag}/h1_none": npy(hn), f"{tag}/c1_none": npy(cn)})
+    save("cell", **out)
+
+
+# ---------------------------------------------------------------- 2. sequence
+def gen_seq():
+    torch.manual_seed(200)
+    lstm = ConvLSTM(4, 8, num_layers=2)
+    T, B, H, W = 5, 2, 12, 12
+    xs = [torch.randn(B, 4, H, W, requires_grad=True) for _ in range(T)]
+    outs, states = lstm(xs)
+    loss = sum((o * o).sum() for o in outs) * 0.5 + states[0][1].sum() + states[1][0].sum()
+    loss.backward()
+    arr = sd_arrays(lstm)
+    arr.update({f"g/{k}": npy(v.grad) for k, v in lstm.named_parameters()})
+    arr["x"] = np.stack([npy(x) for x in xs])
+    arr["gx"] = np.stack([npy(x.grad) for x in xs])
+    arr["out"] = np.stack([npy(o) for o in outs])
+    for li, (h, c) in enumerate(states):
+        arr[f"h_final/{li}"] = npy(h)
+        arr[f"c_final/{li}"] = npy(c)
+    # continuation with carried state
+    with torch.no_grad():
+        outs2, states2 = lstm([x.detach() for x in xs[:2]], [(h.detach(), c.detach()) for h, c in states])
+    arr["out_cont"] = np.stack([npy(o) for o in outs2])
+    save("seq", **arr)
+
+
+# ---------------------------------------------------------------- 3. blocks
+def gen_blocks():
+    arr = {}
+    torch.manual_seed(300)
+    dc = DoubleConv(3, 8)
+    with torch.no_grad():
+        for bn in (dc.net[1], dc.net[4]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    arr.update(sd_arrays(dc, "dc/p/"))
+    xa = torch.randn(4, 3, 10, 10, requires_grad=True)
+    xb = torch.randn(4, 3, 10, 10)
+    dc.train()
+    ya = dc(xa)
+    (ya * torch.linspace(0.5, 1.5, ya.numel()).view_as(ya)).sum().backward()
+    arr["dc/xa"], arr["dc/ya_train"], arr["dc/gxa"] = npy(xa), npy(ya), npy(xa.grad)
+    arr.update({f"dc/g/{k}": npy(v.grad) for k, v in dc.named_parameters()})
+    with torch.no_grad():
+        yb = dc(xb)
+    arr["dc/xb"], arr["dc/yb_train"] = npy(xb), npy(yb)
+    arr.update(sd_arrays(dc, "dc/p_after2/"))
+    dc.eval()
+    with torch.no_grad():
+        arr["dc/ya_eval"] = npy(dc(xa.detach()))
+
+    torch.manual_seed(301)
+    upm = Up(16, 8)
+    arr.update(sd_arrays(upm, "up/p/"))
+    x1 = torch.randn(2, 16, 5, 6, requires_grad=True)
+    x2 = torch.randn(2, 8, 11, 13, requires_grad=True)      # odd skip size: F.pad path
+    upm.train()
+    yu = upm(x1, x2)
+    (yu * yu).sum().backward()
+    arr.update({"up/x1": npy(x1), "up/x2": npy(x2), "up/y_train": npy(yu),
+                "up/gx1": npy(x1.grad), "up/gx2": npy(x2.grad)})
+    arr.update({f"up/g/{k}": npy(v.grad) for k, v in upm.named_parameters()})
+
+    torch.manual_seed(302)
+    dn = Down(8, 16)
+    arr.update(sd_arrays(dn, "down/p/"))
+    xd = torch.randn(2, 8, 12, 12, requires_grad=True)
+    dn.train()
+    yd = dn(xd)
+    (yd * yd).sum().backward()
+    arr.update({"down/x": npy(xd), "down/y_train": npy(yd), "down/gx": npy(xd.grad)})
+    arr.update({f"down/g/{k}": npy(v.grad) for k, v in dn.named_parameters()})
+
+    torch.manual_seed(303)
+    oc = OutConv(8, 1)
+    arr.update(sd_arrays(oc, "outc/p/"))
+    xo = torch.randn(2, 8, 6, 6, requires_grad=True)
+    yo = oc(xo)
+    (yo * yo).sum().backward()
+    arr.update({"outc/x": npy(xo), "outc/y": npy(yo), "outc/gx": npy(xo.grad),
+                "outc/gw": npy(oc.conv.weight.grad), "outc/gb": npy(oc.conv.bias.grad)})
+
+    torch.manual_seed(304)
+    sa = SpatialAttention()
+    arr.update(sd_arrays(sa, "att/p/"))
+    xs = torch.randn(2, 16, 6, 6)
+    with torch.no_grad():
+        arr.update({"att/x": npy(xs), "att/y": npy(sa(xs))})
+    save("blocks", **arr)
+
+
+# ---------------------------------------------------------------- 4/6. model + one optimisation step
+def gen_model(tag, use_skip, seed, lstm_layers=1, use_attention=False, base_ch=4):
+    torch.manual_seed(seed)
+    model = TemporalUNetDualView(1, 1, base_ch=base_ch, lstm_layers=lstm_layers,
+                                 use_skip_lstm=use_skip, use_attention=use_attention)
+    B, T, H, W = 2, 3, 32, 32
+    x = torch.rand(B, T, 2, H, W)
+    y = torch.rand(B, T, 1, H, W) * 2 - 1
+    mask = (torch.rand(B, T, 1, H, W) > 0.3).float()
+    arr = sd_arrays(model, "p/")
+    arr.update({"x": npy(x), "y": npy(y), "mask": npy(mask)})
+
+    # eval-mode forward on the initial weights (+ stateful continuation, no-skip variant only)
+    model.eval()
+    with torch.no_grad():
+        outs, st = model(x)
+        arr["out_eval"] = np.stack([npy(o) for o in outs], axis=1)
+        outs2, _ = model(x[:, :2], st)
+        arr["out_eval_cont"] = np.stack([npy(o) for o in outs2], axis=1)
+        for li, (h, c) in enumerate(st):
+            arr[f"state_h/{li}"], arr[f"state_c/{li}"] = npy(h), npy(c)
+
+    # one full optimisation step exactly as main.py:91-108 (use_mask=True variant)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)     # main.py:275
+    opt.zero_grad(set_to_none=True)
+    output, _ = model(x)
+    y_pred = torch.stack(output, dim=1)
+    loss = ref_main.compute_loss(y_pred, y, mask, True)
+    loss.backward()
+    arr["out_train"] = npy(y_pred)
+    arr["loss"] = npy(loss)
+    arr.update({f"g/{k}": npy(v.grad) for k, v in model.named_parameters()})
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)               # main.py:106
+    arr["grad_norm"] = npy(gn)
+    opt.step()
+    arr.update(sd_arrays(model, "p_after/"))
+    save(tag, **arr)
+
+
+# ---------------------------------------------------------------- 5. loss
+def gen_loss():
+    torch.manual_seed(0)
+    yp = torch.randn(2, 3, 1, 8, 8, requires_grad=True)
+    y = torch.randn(2, 3, 1, 8, 8)
+    mask = (torch.rand(2, 3, 1, 8, 8) > 0.5).float()
+    arr = {"y_pred": npy(yp), "y": npy(y), "mask": npy(mask)}
+    l_un = ref_main.compute_loss(yp, y, mask, use_mask=False)
+    g_un, = torch.autograd.grad(l_un, yp)
+    l_m = ref_main.compute_loss(yp, y, mask, use_mask=True)
+    g_m, = torch.autograd.grad(l_m, yp)
+    arr.update({"loss_unmasked": npy(l_un), "grad_unmasked": npy(g_un),
+                "loss_masked": npy(l_m), "grad_masked": npy(g_m)})
+    print("loss known answers:", float(l_un.detach()), float(l_m.detach()))
+    save("loss", **arr)
+
+
+# ---------------------------------------------------------------- 7. dataset transform (8f-2)
+def gen_dataset():
+    rng = np.random.default_rng(7)
+    N, T, H, W = 3, 4, 8, 8
+    X = (rng.random((N, T, 2, H, W)) * 40).astype(np.float32)
+    X[X < 8] = 0.0
+    Y = (rng.standard_normal((N, T, 1, H, W)) * 3).astype(np.float32)
+    path = os.path.join(OUT, "_tmp_ds.npz")
+    np.savez(path, X=X, Y=Y)
+    ds = NPZSequenceDataset(path)
+    os.remove(path)
+    x, y, m = ds[1]
+    arr = {"X": X, "Y": Y, "x1": npy(x), "y1": npy(y), "mask1": npy(m),
+           "norm_const": np.float64(ds.norm_const), "min_vel": np.float64(ds.min_vel),
+           "max_vel": np.float64(ds.max_vel), "y_scale": np.float64(ds.y_scale),
+           "trans_min": np.float64(ds.trans_min), "trans_max": np.float64(ds.trans_max),
+           "denorm_y1": npy(ds.denormalize(y))}
+    save("dataset", **arr)
+
+
+if __name__ == "__main__":
+    gen_cell()
+    gen_seq()
+    gen_blocks()
+    gen_loss()
+    gen_model("model_noskip", use_skip=False, seed=400)
+    gen_model("model_skip", use_skip=True, seed=401)
+    gen_model("model_2layer_att", use_skip=False, seed=402, lstm_layers=2, use_attention=True, base_ch=2)
+    gen_dataset()
