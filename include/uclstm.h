@@ -1,0 +1,249 @@
+/*
+ * uclstm.h -- C ABI of libuclstm.so, the MI355X (gfx950) UNet-ConvLSTM hot path.
+ *
+ * The reference (dordanino12/unet-convlstm) has no FFI layer: its boundary is the
+ * Python nn.Module surface of train/unet.py.  This header is what that surface binds
+ * to underneath (see INTEGRATION.md for the ctypes stub): every entry point takes plain
+ * device pointers, sizes and a hipStream_t (passed as void*), launches asynchronously
+ * on that stream, allocates nothing, never synchronises, and returns 0 or a negative
+ * UCLSTM_E_* code (the host mirror turns those into Python exceptions).
+ *
+ * Data layout in HBM:
+ *   activations  bf16, NHWC, channel count padded to a multiple of 8 ("Cp"), pad = 0
+ *   cell state   f32,  NHWC, Cp channels
+ *   weights      repacked from the reference's f32 OIHW into bf16 [N][Ktot] panels,
+ *                K ordered (tap, source, channel) with every (tap, source) segment padded
+ *                to a multiple of 64 (uclstm_pack_weights)
+ *
+ * Each function cites the reference lines (relative to the reference checkout) whose
+ * eager ATen calls it replaces.
+ */
+#ifndef UCLSTM_H
+#define UCLSTM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCLSTM_ABI_VERSION 1
+
+#define UCLSTM_OK            0
+#define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
+#define UCLSTM_E_LAUNCH     -2   /* hipLaunchKernel reported an error (hipGetLastError)      */
+#define UCLSTM_E_NODEVICE   -3   /* no gfx950 device visible                                 */
+
+/* ------------------------------------------------------------------------------------ */
+/* Implicit-GEMM convolution family                                                     */
+/* ------------------------------------------------------------------------------------ */
+
+/* One input tensor of a (possibly channel-concatenated) convolution:
+ * bf16 [n_img][Hs][Ws][C], placed at (offY, offX) inside the output pixel frame
+ * (the F.pad of train/unet.py:95-97; 0 when sizes match). */
+typedef struct {
+    const void* ptr;
+    int32_t C;          /* padded channel count, multiple of 8 */
+    int32_t Hs, Ws;
+    int32_t offY, offX;
+} uclstm_src;
+
+/* One destination of the epilogue: columns [n_begin, n_end) of the GEMM go to channels
+ * [c_off, c_off + n_end - n_begin) of bf16 [n_img][Hd][Wd][C] at pixel
+ * (y*scale + oy, x*scale + ox); pixels falling outside are dropped.
+ * The wgrad kernel READS its dY operand through the same table. */
+typedef struct {
+    void* ptr;
+    int32_t n_begin, n_end;     /* multiples of 8 */
+    int32_t C, c_off;
+    int32_t Hd, Wd;
+    int32_t scale, oy, ox;
+} uclstm_seg;
+
+#define UCLSTM_EPI_STORE 0   /* bias (+ per-column affine, ReLU) -> bf16 segments (+ BN partial sums) */
+#define UCLSTM_EPI_LSTM  1   /* gate nonlinearities + cell update, train/unet.py:29-35                */
+
+typedef struct {
+    /* output pixel grid: n_img images of H x W; BatchNorm statistic groups (timesteps)
+     * are `groups` equal runs of images (train/unet.py:179, :196 call BN once per t). */
+    int32_t n_img, H, W, groups;
+    /* tap geometry: source pixel = (y*scale + tap/ktap - pad - offY, x*scale + tap%ktap - pad - offX)
+     *   3x3 pad 1 conv: ktap 3, scale 1, pad 1      1x1 conv / plain GEMM: ktap 1, scale 1, pad 0
+     *   ConvTranspose2d(k2,s2) input-gradient gather: ktap 2, scale 2, pad 0 */
+    int32_t ktap, scale, pad;
+    int32_t nsrc;
+    uclstm_src src[2];
+    /* packed weights bf16 [N][Ktot], Ktot = ktap*ktap*(kseg[0]+kseg[1]), kseg[s] = roundup(src[s].C, 64) */
+    const void* wp;
+    int32_t N, Ktot;
+    const float* bias;           /* [N] f32 or NULL */
+    const float* col_scale;      /* [N] optional per-column scale  (eval-mode BatchNorm fold) */
+    const float* col_shift;      /* [N] optional per-column shift  */
+    int32_t relu;
+    int32_t epi;
+    /* UCLSTM_EPI_STORE */
+    int32_t nseg;
+    uclstm_seg seg[4];
+    float* stats;                /* optional [groups][tiles_per_group][N][2] partial (sum, sumsq) of the STORED bf16 values */
+    /* UCLSTM_EPI_LSTM: N = 64*ceil(Hd/16) gate-interleaved rows */
+    int32_t Hd_p;                /* padded hidden channels, multiple of 8 */
+    const float* c_prev;         /* f32 [pixels][Hd_p] or NULL (zero state, train/unet.py:23-25) */
+    float* c_out;                /* f32 [pixels][Hd_p] */
+    void* h_out;                 /* bf16 [pixels][Hd_p] */
+    void* gates_out;             /* bf16 [pixels][4][Hd_p] post-activation i,f,g,o or NULL (inference) */
+} uclstm_igemm_desc;
+
+/* Rows of `stats` per group for a descriptor: ceil((n_img/groups)*H*W / 128). */
+int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups);
+
+/* out = conv(src) as one MFMA implicit GEMM.  Replaces, depending on the descriptor:
+ *   nn.Conv2d 3x3 of DoubleConv (train/unet.py:70-71) incl. the cat([skip, up]) of :98,
+ *   its input gradient (flipped/transposed panel), ConvTranspose2d forward and input
+ *   gradient (:90,:94), and with UCLSTM_EPI_LSTM the whole ConvLSTMCell.forward (:21-36:
+ *   cat + conv + chunk + sigmoid/tanh + cell update in one kernel). */
+int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* d, void* stream);
+
+/* Weight gradient  dWp[n][k] (+)= sum_pixels dY[pixel][n] * A[pixel][k]  (f32 [N][Ktot], same
+ * K order as the forward panel).  dY is read through seg[] (nseg >= 1); `splits` pixel ranges
+ * accumulate with f32 atomics, so dWp must be zeroed by the caller when splits > 1 or
+ * accumulate != 0.  Replaces the autograd weight-gradient of the convolutions above. */
+typedef struct {
+    int32_t n_img, H, W;
+    int32_t ktap, scale, pad;
+    int32_t nsrc;
+    uclstm_src src[2];
+    int32_t N, Ktot;
+    int32_t nseg;
+    uclstm_seg seg[4];
+    float* dwp;
+    int32_t splits;
+    int32_t accumulate;
+} uclstm_wgrad_desc;
+int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Weight panels                                                                        */
+/* ------------------------------------------------------------------------------------ */
+#define UCLSTM_NMODE_IDENTITY 0   /* row n <-> entity n (valid n < n_valid)                               */
+#define UCLSTM_NMODE_LSTM     1   /* gate-interleaved: n = hb*64 + gate*16 + j <-> gate*n_valid + hb*16 + j */
+#define UCLSTM_NMODE_TAPMAJOR 2   /* n = tapn*n_cp + co (ConvTranspose forward), valid co < n_valid        */
+#define UCLSTM_KMODE_IDENTITY 0   /* channel c of source s <-> choff[s] + c (valid c < cvalid[s])          */
+#define UCLSTM_KMODE_GATES    1   /* c = gate*k_hdp + hc <-> gate*k_hd + hc (valid hc < k_hd)              */
+#define UCLSTM_KMODE_IM2COL   2   /* c = tap*k_hd + ci (pre-gathered first layer), tap < k_hdp             */
+
+typedef struct {
+    int32_t N, Ktot;
+    int32_t taps, nsrc;
+    int32_t kseg[2], cvalid[2], choff[2];
+    int32_t n_mode, n_valid, n_cp;
+    int32_t k_mode, k_hdp, k_hd;
+    int32_t tap_flip;
+    /* element offset in the f32 source tensor = n_ent*stride_n + k_ent*stride_k
+     *                                         + tap_eff*stride_tap + tapn*stride_ntap */
+    int64_t stride_n, stride_k, stride_tap, stride_ntap;
+} uclstm_pack_desc;
+
+/* f32 reference layout (OIHW conv weight, train/unet.py:19,:70; [in,out,2,2] convT weight, :90)
+ * -> bf16 panel [N][Ktot] (zero padded). */
+int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream);
+/* f32 panel gradient [N][Ktot] -> f32 gradient in the reference layout:
+ * grad = (accumulate ? grad : 0) + dWp  on every valid element. */
+int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, float* grad, int32_t accumulate, void* stream);
+/* bias [n_valid*(4 if LSTM)] f32 -> panel-row order [N] f32 (zero padded). */
+int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* BatchNorm2d + ReLU (train/unet.py:70-71), per-timestep statistics                    */
+/* ------------------------------------------------------------------------------------ */
+/* From the conv epilogue's partial sums build, per (group, channel): scale = gamma*rstd,
+ * shift = beta - mean*scale, mean, rstd; then update running_mean/var with momentum 0.1 and
+ * the unbiased variance, once per group IN ORDER (the reference calls BN once per timestep). */
+int32_t uclstm_bn_finalize(const float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
+                           int64_t count_per_group, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps,
+                           float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* a = relu(z*scale[g] + shift[g]),  g = pixel / pixels_per_group;  z, a bf16 [pixels][Cp]. */
+int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift,
+                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
+/* Backward pass 1: sums[g][c] = (sum g_, sum g_*xhat), g_ = dA * [scale*z+shift > 0]; sums must be zeroed. */
+int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, float* sums,
+                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
+/* Backward pass 2: dz = scale*(g_ - s1/n - xhat*s2/n)  (bf16). */
+int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, const float* shift,
+                            const float* mean, const float* rstd, const float* sums, void* dz,
+                            int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* MaxPool2d(2) (train/unet.py:81)                                                      */
+/* ------------------------------------------------------------------------------------ */
+int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream);
+/* da must be zero-filled by the caller when H or W is odd. First maximum in window scan order wins (ATen rule). */
+int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* ConvLSTM backward point-wise part (autograd of train/unet.py:29-35)                  */
+/* ------------------------------------------------------------------------------------ */
+/* dh = dh_a (+ dh_b); dc = dc_io + dh*o*(1-tanh(c)^2); dgates = pre-activation gradients
+ * bf16 [pixels][4][Hd_p] (i,f,g,o); dc_io <- dc*f (gradient w.r.t. c_prev). */
+int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new,
+                                  const void* dh_a, const void* dh_b, float* dc_io, int32_t dc_is_zero,
+                                  void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Layout / boundary kernels                                                            */
+/* ------------------------------------------------------------------------------------ */
+/* f32 NCHW [..] -> bf16 NHWC with channel padding. Image i of the output reads image
+ * (i % inner)*outer_stride + (i / inner)*inner_stride of the input (elements), which lets
+ * [B,T,C,H,W] be read time-major (train/unet.py:180 indexes x_seq[:, t]). */
+int32_t uclstm_nchw_to_nhwc(const float* x, void* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                            int32_t inner, int64_t inner_stride, int64_t outer_stride, void* stream);
+int32_t uclstm_nhwc_to_nchw(const void* a, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W, void* stream);
+/* Gradient of the above (f32 NCHW -> bf16 NHWC is linear): */
+int32_t uclstm_nchw_grad_to_nhwc(const float* g, void* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W, void* stream);
+/* First-layer gather: out[img][y][x][tap*C + c] = x[img'][c][y+dy-1][x+dx-1] (zero outside), Kp = padded 9*C. */
+int32_t uclstm_im2col3x3_first(const float* x, void* out, int32_t n_img, int32_t C, int32_t Kp, int32_t H, int32_t W,
+                               int32_t inner, int64_t inner_stride, int64_t outer_stride, void* stream);
+/* f32 [pixels][Cp] <-> NCHW for the cell state at module boundaries. */
+int32_t uclstm_nchw_to_nhwc_f32(const float* x, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W, void* stream);
+int32_t uclstm_nhwc_to_nchw_f32(const float* a, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* OutConv 1x1 (train/unet.py:101-107): bf16 NHWC in, f32 NCHW out                      */
+/* ------------------------------------------------------------------------------------ */
+int32_t uclstm_outconv_fwd(const void* a, const float* w, const float* b, float* y,
+                           int64_t n_img, int32_t HW, int32_t Cp, int32_t C, int32_t Co, void* stream);
+/* da bf16 [pixels][Cp]; dw [Co][C], db [Co] accumulate with atomics (caller zeroes). */
+int32_t uclstm_outconv_bwd(const void* a, const float* w, const float* dy, void* da, float* dw, float* db,
+                           int64_t n_img, int32_t HW, int32_t Cp, int32_t C, int32_t Co, void* stream);
+
+/* column sums of a bf16 [pixels][Cp] tensor into f32 [Cp] (bias gradients); out must be zeroed. */
+int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int32_t Cp, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Loss (main.py:28-72) -- weighted L1 + 0.005 * gradient L1, f32 [n][H][W] planes      */
+/* ------------------------------------------------------------------------------------ */
+/* sums[0..3] = sum(ad*w*m), sum(w*m), sum(gd*mc), sum(mc)  (m = 1 when mask == NULL); caller zeroes sums. */
+int32_t uclstm_loss_fwd(const float* y_pred, const float* y, const float* mask, double* sums,
+                        int64_t planes, int32_t H, int32_t W, void* stream);
+/* grad = coefs[0] * d(sum ad*w*m)/dy_pred + coefs[1] * d(sum gd*mc)/dy_pred; coefs is a DEVICE f32[2]
+ * (1/denominators times the upstream gradient), so the step never syncs with the host. */
+int32_t uclstm_loss_bwd(const float* y_pred, const float* y, const float* mask, const float* coefs,
+                        float* grad, int64_t planes, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Optimiser (main.py:106-108): global-norm clip + AdamW on flat f32 buffers            */
+/* ------------------------------------------------------------------------------------ */
+int32_t uclstm_sumsq(const float* g, int64_t n, double* out /* accumulates, caller zeroes */, void* stream);
+/* p,m,v,g flat f32 [n]; grad is scaled by min(1, max_norm/(sqrt(*sumsq)+1e-6)) read on device (no host sync). */
+int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* Library self-description (used by the loader to check the build). */
+int32_t uclstm_abi_version(void);
+const char* uclstm_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCLSTM_H */

@@ -1,0 +1,429 @@
+"""GPU parity tests of the HIP operators (through the C ABI) against the CPU oracle.
+
+Tolerance model (stated): kernels take bf16 operands and accumulate in f32.
+Operator tests feed the oracle the SAME bf16-rounded operands, so the only differences are f32
+summation order and the final bf16 rounding of stored activations (2^-9 relative):
+  * bf16 outputs:  rel-L2 <= 4e-3 and max-abs <= 1.2e-2 * max|ref|
+  * f32 outputs (weight gradients, cell state, loss): rel-L2 <= 2e-3
+Golden-fixture tests (f32 reference, un-rounded operands) use rel-L2 <= 1e-2 on outputs and
+<= 3e-2 on gradients.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, sub, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import unet_convlstm_amd as U
+    from unet_convlstm_amd import ops
+from oracle import unet_oracle as O
+
+DEV = "cuda"
+
+
+def cpad(c):
+    return (c + 7) // 8 * 8
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def to_nhwc(x):
+    N, C, H, W = x.shape
+    t = torch.zeros(N, H, W, cpad(C))
+    t[..., :C] = x.permute(0, 2, 3, 1)
+    return t.to(torch.bfloat16).to(DEV).contiguous()
+
+
+def from_nhwc(a, C):
+    return a[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def check_bf16(got, ref, what, l2=4e-3, mx=1.2e-2):
+    e = rel_l2(got, ref)
+    m = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert e <= l2 and m <= mx, f"{what}: rel-L2 {e:.3e} (<= {l2}), max-rel {m:.3e} (<= {mx})"
+
+
+def check_f32(got, ref, what, l2=2e-3):
+    e = rel_l2(got, ref)
+    assert e <= l2, f"{what}: rel-L2 {e:.3e} (<= {l2})"
+
+
+def pad_is_zero(a, C):
+    return bool((a[..., C:] == 0).all())
+
+
+# ---------------------------------------------------------------------------------------------
+# layout kernels
+# ---------------------------------------------------------------------------------------------
+def test_layout_roundtrip_and_im2col():
+    torch.manual_seed(0)
+    x = torch.randn(3, 5, 7, 9)
+    a = ops.ToNHWC.apply(x.to(DEV))
+    assert a.shape == (3, 7, 9, 8) and pad_is_zero(a, 5)
+    assert torch.equal(a.cpu(), to_nhwc(x).cpu())
+    back = ops.FromNHWC.apply(a, 5)
+    assert torch.equal(back.cpu(), bf(x))
+    c = torch.randn(2, 5, 4, 6)
+    cn = ops.StateToNHWC.apply(c.to(DEV))
+    assert torch.equal(ops.StateFromNHWC.apply(cn, 5).cpu(), c)
+    # time-major im2col of [B,T,C,H,W]
+    xs = torch.rand(2, 3, 2, 6, 5)
+    g = ops.im2col_first(xs.to(DEV), True)          # [T*B,H,W,24]
+    assert g.shape == (6, 6, 5, 24)
+    cols = F.unfold(xs.transpose(0, 1).reshape(6, 2, 6, 5), 3, padding=1)      # [6, C*9, HW], index c*9+tap
+    cols = cols.view(6, 2, 9, 6, 5).permute(0, 3, 4, 2, 1).reshape(6, 6, 5, 18)  # -> tap*C + c
+    assert torch.equal(g[..., :18].float().cpu(), bf(cols))
+    assert pad_is_zero(g, 18)
+
+
+# ---------------------------------------------------------------------------------------------
+# implicit GEMM forward: conv3x3 (1 and 2 sources, offsets), shapes off the tile grid
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C0,C1,Co,H,W", [
+    (2, 8, 0, 8, 5, 7),          # tiny, M < one tile
+    (3, 24, 0, 40, 9, 11),       # channel tails (24 of 64, 40 of 128), M = 297
+    (2, 72, 0, 136, 12, 13),     # K segment 128 with tail, two N tiles
+    (2, 16, 8, 16, 10, 10),      # two sources
+    (1, 64, 64, 64, 16, 16),     # exact tiles
+])
+def test_conv3x3_forward(N, C0, C1, Co, H, W):
+    torch.manual_seed(1)
+    Ci = C0 + C1
+    x0 = bf(torch.randn(N, C0, H, W))
+    w = bf(torch.randn(Co, Ci, 3, 3) * 0.2)
+    b = torch.randn(Co)
+    srcs = [ops.SrcView(to_nhwc(x0))]
+    xin = x0
+    cv, cp = [C0], [cpad(C0)]
+    if C1:
+        x1 = bf(torch.randn(N, C1, H, W))
+        srcs.append(ops.SrcView(to_nhwc(x1)))
+        xin = torch.cat((x0, x1), 1)
+        cv, cp = [C0, C1], [cpad(C0), cpad(C1)]
+    pd = ops.conv_pack_desc(Co, Ci, cv, cp)
+    wp = ops.pack_weights(pd, w.to(DEV))
+    bp = ops.pack_bias(pd, b.to(DEV))
+    out = torch.full((N, H, W, cpad(Co)), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.igemm_store(srcs, wp, (H, W), N, [(out, 0, cpad(Co), 0, 1, 0, 0)], ktap=3, pad=1, bias=bp)
+    ref = F.conv2d(xin, w, b, padding=1)
+    check_bf16(from_nhwc(out, Co), ref, "conv3x3")
+    assert pad_is_zero(out, Co)
+
+
+def test_conv3x3_padded_second_source_and_groups_stats():
+    """cat([skip, up]) with the upsampled map smaller than the skip (F.pad offsets) + per-group BN partial sums."""
+    torch.manual_seed(2)
+    N, H, W, groups = 4, 11, 13, 2
+    x0 = bf(torch.randn(N, 8, H, W))
+    u = bf(torch.randn(N, 8, 10, 12))
+    w = bf(torch.randn(16, 16, 3, 3) * 0.2)
+    pd = ops.conv_pack_desc(16, 16, [8, 8], [8, 8])
+    wp = ops.pack_weights(pd, w.to(DEV))
+    out = torch.empty((N, H, W, 16), dtype=torch.bfloat16, device=DEV)
+    tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups)
+    stats = torch.zeros((groups, tpg, 16, 2), device=DEV)
+    ops.igemm_store([ops.SrcView(to_nhwc(x0)), ops.SrcView(to_nhwc(u), 0, 0)], wp, (H, W), N, [(out, 0, 16, 0, 1, 0, 0)],
+                    ktap=3, pad=1, groups=groups, stats=stats)
+    up = F.pad(u, [0, 1, 0, 1])
+    ref = F.conv2d(torch.cat((x0, up), 1), w, None, padding=1)
+    check_bf16(from_nhwc(out, 16), ref, "conv3x3 two-source padded")
+    got = from_nhwc(out, 16)
+    s = stats.sum(dim=1).cpu()
+    for g in range(groups):
+        blk = got[g * 2:(g + 1) * 2]
+        torch.testing.assert_close(s[g, :, 0], blk.sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-2)
+        torch.testing.assert_close(s[g, :, 1], (blk * blk).sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# weight gradient (ds_read_b64_tr_b16 path)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C0,C1,Co,H,W", [
+    (2, 8, 0, 8, 5, 7),
+    (3, 24, 0, 40, 9, 11),
+    (2, 136, 0, 72, 6, 7),
+    (2, 16, 8, 16, 10, 10),
+    (4, 64, 0, 128, 16, 16),
+])
+def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
+    torch.manual_seed(3)
+    Ci = C0 + C1
+    x0 = bf(torch.randn(N, C0, H, W))
+    dy = bf(torch.randn(N, Co, H, W))
+    srcs = [ops.SrcView(to_nhwc(x0))]
+    xin = x0
+    cv, cp = [C0], [cpad(C0)]
+    if C1:
+        x1 = bf(torch.randn(N, C1, H, W))
+        srcs.append(ops.SrcView(to_nhwc(x1)))
+        xin = torch.cat((x0, x1), 1)
+        cv, cp = [C0, C1], [cpad(C0), cpad(C1)]
+    pd = ops.conv_pack_desc(Co, Ci, cv, cp)
+    dyn = to_nhwc(dy)
+    dwp = ops.igemm_wgrad(srcs, [(dyn, 0, cpad(Co), 0, 1, 0, 0)], pd.N, pd.Ktot, (H, W), N, ktap=3, pad=1)
+    w = torch.zeros(Co, Ci, 3, 3)
+    got = ops.unpack_wgrad(pd, dwp, w.to(DEV)).cpu()
+    wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    (F.conv2d(xin, wr, None, padding=1) * dy).sum().backward()
+    check_f32(got, wr.grad, "conv3x3 wgrad")
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd operators vs oracle on bf16-rounded operands
+# ---------------------------------------------------------------------------------------------
+def test_conv_bn_relu_train_fwd_bwd_two_groups():
+    torch.manual_seed(4)
+    N, Ci, Co, H, W, groups = 4, 16, 24, 9, 8, 2
+    x = bf(torch.randn(N, Ci, H, W))
+    w = bf(torch.randn(Co, Ci, 3, 3) * 0.2)
+    b = torch.randn(Co) * 0.1
+    gamma, beta = torch.rand(Co) + 0.5, torch.randn(Co) * 0.2
+    rm, rv = torch.zeros(Co), torch.ones(Co)
+    go = torch.randn(N, Co, H, W)
+
+    xg = to_nhwc(x).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    gg, bg = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    bb = b.to(DEV).requires_grad_(True)
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    a = ops.ConvBNReLU.apply(xg, None, wg, bb, gg, bg, rmg, rvg, (Ci,), (0, 0), groups, True, 0.1, 1e-5, False)
+    a.backward(to_nhwc(go))
+
+    # oracle: BN once per group, in order
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    p = {"bn.weight": gr, "bn.bias": br, "bn.running_mean": rm.clone(), "bn.running_var": rv.clone(),
+         "bn.num_batches_tracked": torch.tensor(0)}
+    buf = {}
+    outs = []
+    for g in range(groups):
+        z = F.conv2d(xr[g * 2:(g + 1) * 2], wr, b, padding=1)
+        outs.append(O.batchnorm_relu(z, p, "bn", True, buf))
+    ref = torch.cat(outs)
+    (ref * bf(go)).sum().backward()
+    check_bf16(from_nhwc(a.detach(), Co), ref.detach(), "conv+bn+relu fwd", l2=6e-3, mx=2e-2)
+    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "conv+bn+relu dx", l2=1.5e-2, mx=5e-2)
+    check_f32(wg.grad.cpu(), wr.grad, "conv+bn+relu dW", l2=1.5e-2)
+    check_f32(gg.grad.cpu(), gr.grad, "dgamma", l2=1e-2)
+    check_f32(bg.grad.cpu(), br.grad, "dbeta", l2=1e-2)
+    torch.testing.assert_close(rmg.cpu(), buf["bn.running_mean"], rtol=5e-3, atol=2e-3)
+    torch.testing.assert_close(rvg.cpu(), buf["bn.running_var"], rtol=5e-3, atol=2e-3)
+
+
+def test_maxpool_fwd_bwd_matches_aten_rule():
+    torch.manual_seed(5)
+    x = bf(torch.randn(2, 12, 7, 10))
+    x[0, :, 0:2, 0:2] = 1.0                     # a tie: first element in scan order must win
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2)
+    go = bf(torch.randn_like(ref))
+    ref.backward(go)
+    xg = to_nhwc(x).requires_grad_(True)
+    p = ops.MaxPool2.apply(xg)
+    p.backward(to_nhwc(go))
+    assert torch.equal(from_nhwc(p.detach(), 12), ref.detach())
+    assert torch.equal(from_nhwc(xg.grad, 12), xr.grad)
+
+
+def test_convtranspose_fwd_bwd():
+    torch.manual_seed(6)
+    N, Ci, Co, h, w_ = 2, 24, 12, 5, 6
+    x = bf(torch.randn(N, Ci, h, w_))
+    w = bf(torch.randn(Ci, Co, 2, 2) * 0.3)
+    b = torch.randn(Co) * 0.1
+    go = bf(torch.randn(N, Co, 2 * h, 2 * w_))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, stride=2)
+    ref.backward(go)
+    xg = to_nhwc(x).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    u = ops.ConvT2x2.apply(xg, wg, bg)
+    u.backward(to_nhwc(go))
+    check_bf16(from_nhwc(u.detach(), Co), ref.detach(), "convT fwd")
+    assert pad_is_zero(u.detach(), Co)
+    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "convT dx")
+    check_f32(wg.grad.cpu(), wr.grad, "convT dW")
+    check_f32(bg.grad.cpu(), br.grad, "convT db")
+
+
+def test_outconv_fwd_bwd():
+    torch.manual_seed(7)
+    N, Ci, Co, H, W = 3, 12, 2, 6, 7
+    x = bf(torch.randn(N, Ci, H, W))
+    w, b = torch.randn(Co, Ci, 1, 1) * 0.3, torch.randn(Co)
+    go = torch.randn(N, Co, H, W)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    ref.backward(go)
+    xg = to_nhwc(x).requires_grad_(True)
+    wg, bg = w.view(Co, Ci).to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.OutConv1x1.apply(xg, wg, bg)
+    y.backward(go.to(DEV))
+    check_f32(y.detach().cpu(), ref.detach(), "outconv fwd", l2=1e-5)
+    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "outconv dx")
+    check_f32(wg.grad.cpu().view_as(wr.grad), wr.grad, "outconv dW", l2=1e-4)
+    check_f32(bg.grad.cpu(), br.grad, "outconv db", l2=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvLSTM: golden fixtures from the reference (f32) and the sequence driver
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_convlstm_cell_golden(tag):
+    f = sub(load_golden("cell"), tag + "/")
+    hd, cin = f["h0"].shape[1], f["x"].shape[1]
+    cell = U.ConvLSTMCell(cin, hd).to(DEV)
+    with torch.no_grad():
+        cell.conv.weight.copy_(f["weight"])
+        cell.conv.bias.copy_(f["bias"])
+    x = f["x"].to(DEV).requires_grad_(True)
+    h0 = f["h0"].to(DEV).requires_grad_(True)
+    c0 = f["c0"].to(DEV).requires_grad_(True)
+    h1, (h1b, c1) = cell(x, (h0, c0))
+    assert h1 is h1b and h1.dtype == torch.float32 and h1.shape == f["h1"].shape
+    (h1.sum() + c1.sum()).backward()
+    check_bf16(h1.detach().cpu(), f["h1"], "cell h1", l2=1e-2, mx=3e-2)
+    check_f32(c1.detach().cpu(), f["c1"], "cell c1", l2=1e-2)
+    check_f32(x.grad.cpu(), f["gx"], "cell dx", l2=3e-2)
+    check_f32(h0.grad.cpu(), f["gh0"], "cell dh0", l2=3e-2)
+    check_f32(c0.grad.cpu(), f["gc0"], "cell dc0", l2=3e-2)
+    check_f32(cell.conv.weight.grad.cpu(), f["gw"], "cell dW", l2=3e-2)
+    check_f32(cell.conv.bias.grad.cpu(), f["gb"], "cell db", l2=3e-2)
+    with torch.no_grad():
+        hn, (_, cn) = cell(f["x"].to(DEV))
+    check_bf16(hn.cpu(), f["h1_none"], "cell h1 (state=None)", l2=1e-2, mx=3e-2)
+    check_f32(cn.cpu(), f["c1_none"], "cell c1 (state=None)", l2=1e-2)
+
+
+def test_convlstm_two_layer_sequence_golden():
+    g = load_golden("seq")
+    lstm = U.ConvLSTM(4, 8, num_layers=2).to(DEV)
+    lstm.load_state_dict({k: v for k, v in sub(g, "p/").items()})
+    xs = [g["x"][t].to(DEV).requires_grad_(True) for t in range(g["x"].shape[0])]
+    outs, states = lstm(xs)
+    loss = sum((o * o).sum() for o in outs) * 0.5 + states[0][1].sum() + states[1][0].sum()
+    loss.backward()
+    check_bf16(torch.stack([o.detach().cpu() for o in outs]), g["out"], "seq out", l2=1e-2, mx=4e-2)
+    for li in range(2):
+        check_f32(states[li][0].detach().cpu(), g[f"h_final/{li}"], f"h_final {li}", l2=1e-2)
+        check_f32(states[li][1].detach().cpu(), g[f"c_final/{li}"], f"c_final {li}", l2=1e-2)
+    check_f32(torch.stack([x.grad.cpu() for x in xs]), g["gx"], "seq dx", l2=3e-2)
+    for k, v in lstm.named_parameters():
+        check_f32(v.grad.cpu(), g["g/" + k], "seq grad " + k, l2=3e-2)
+    with torch.no_grad():
+        outs2, _ = lstm([x.detach() for x in xs[:2]], [(h.detach(), c.detach()) for h, c in states])
+    check_bf16(torch.stack([o.cpu() for o in outs2]), g["out_cont"], "seq continuation", l2=1.5e-2, mx=5e-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks: golden fixtures
+# ---------------------------------------------------------------------------------------------
+def test_double_conv_golden_train_eval_running_stats():
+    g = sub(load_golden("blocks"), "dc/")
+    dc = U.DoubleConv(3, 8).to(DEV)
+    dc.load_state_dict(sub(g, "p/"))
+    dc.train()
+    xa = g["xa"].to(DEV).requires_grad_(True)      # requires grad -> generic 3x3 path
+    ya = dc(xa)
+    (ya * torch.linspace(0.5, 1.5, ya.numel(), device=DEV).view_as(ya)).sum().backward()
+    check_bf16(ya.detach().cpu(), g["ya_train"], "DoubleConv train", l2=1.5e-2, mx=6e-2)
+    check_f32(xa.grad.cpu(), g["gxa"], "DoubleConv dx", l2=4e-2)
+    for k, v in dc.named_parameters():
+        ref = g["g/" + k]
+        if k in ("net.0.bias", "net.3.bias"):
+            assert float(v.grad.abs().max()) <= 1e-6          # analytically zero (bias in front of BN)
+            continue
+        check_f32(v.grad.cpu(), ref, "DoubleConv grad " + k, l2=4e-2)
+    with torch.no_grad():
+        yb = dc(g["xb"].to(DEV))                   # no grad -> pre-gathered first layer path
+    check_bf16(yb.cpu(), g["yb_train"], "DoubleConv train (im2col path)", l2=1.5e-2, mx=6e-2)
+    after = sub(g, "p_after2/")
+    sd = dc.state_dict()
+    for k in ("net.1.running_mean", "net.1.running_var", "net.4.running_mean", "net.4.running_var"):
+        torch.testing.assert_close(sd[k].cpu(), after[k], rtol=2e-2, atol=3e-3)
+    assert int(sd["net.1.num_batches_tracked"]) == 2 and int(sd["net.4.num_batches_tracked"]) == 2
+    dc.eval()
+    with torch.no_grad():
+        ye = dc(g["xa"].to(DEV))
+    # eval uses this run's own (bf16-path) running stats; compare against the oracle on those buffers
+    p = {"dc." + k: v.detach().cpu().clone() for k, v in dc.state_dict().items()}
+    ref = O.double_conv(g["xa"], p, "dc", False, None)
+    check_bf16(ye.cpu(), ref, "DoubleConv eval", l2=1.5e-2, mx=6e-2)
+
+
+def test_up_down_golden():
+    allb = load_golden("blocks")
+    g = sub(allb, "up/")
+    up = U.Up(16, 8).to(DEV)
+    up.load_state_dict(sub(g, "p/"))
+    up.train()
+    x1 = g["x1"].to(DEV).requires_grad_(True)
+    x2 = g["x2"].to(DEV).requires_grad_(True)
+    y = up(x1, x2)
+    (y * y).sum().backward()
+    check_bf16(y.detach().cpu(), g["y_train"], "Up fwd (odd skip)", l2=1.5e-2, mx=6e-2)
+    check_f32(x1.grad.cpu(), g["gx1"], "Up dx1", l2=4e-2)
+    check_f32(x2.grad.cpu(), g["gx2"], "Up dx2", l2=4e-2)
+    for k, v in up.named_parameters():
+        if k.endswith("net.0.bias") or k.endswith("net.3.bias"):
+            continue
+        check_f32(v.grad.cpu(), g["g/" + k], "Up grad " + k, l2=4e-2)
+
+    g = sub(allb, "down/")
+    dn = U.Down(8, 16).to(DEV)
+    dn.load_state_dict(sub(g, "p/"))
+    dn.train()
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = dn(x)
+    (y * y).sum().backward()
+    check_bf16(y.detach().cpu(), g["y_train"], "Down fwd", l2=1.5e-2, mx=6e-2)
+    check_f32(x.grad.cpu(), g["gx"], "Down dx", l2=5e-2)
+
+    g = sub(allb, "outc/")
+    oc = U.OutConv(8, 1).to(DEV)
+    oc.load_state_dict(sub(g, "p/"))
+    with torch.no_grad():
+        check_f32(oc(g["x"].to(DEV)).cpu(), g["y"], "OutConv", l2=5e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# loss and optimiser
+# ---------------------------------------------------------------------------------------------
+def test_loss_golden():
+    g = load_golden("loss")
+    for tag, use_mask in (("unmasked", False), ("masked", True)):
+        yp = g["y_pred"].to(DEV).requires_grad_(True)
+        loss = U.compute_loss(yp, g["y"].to(DEV), g["mask"].to(DEV), use_mask)
+        torch.testing.assert_close(loss.cpu(), g["loss_" + tag], rtol=1e-5, atol=1e-6)
+        loss.backward()
+        torch.testing.assert_close(yp.grad.cpu(), g["grad_" + tag], rtol=1e-4, atol=1e-7)
+
+
+def test_fused_adamw_with_clip_matches_oracle():
+    torch.manual_seed(8)
+    shapes = [(7, 3), (5,), (4, 2, 3, 3), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    opt = U.FusedAdamW(ps, lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    ref_p = {str(i): p.detach().cpu().clone() for i, p in enumerate(ps)}
+    m = {k: torch.zeros_like(v) for k, v in ref_p.items()}
+    v = {k: torch.zeros_like(t) for k, t in ref_p.items()}
+    for step in (1, 2, 3):
+        grads = {str(i): torch.randn(s) * (3.0 if step == 1 else 0.05) for i, s in enumerate(shapes)}
+        opt.zero_grad()
+        for i, p in enumerate(ps):
+            p.grad.copy_(grads[str(i)])
+        opt.step()
+        clipped, total = O.clip_grad_norm(grads, 1.0)
+        torch.testing.assert_close(opt.grad_norm().float().cpu().view(()), total, rtol=1e-5, atol=1e-6)
+        ref_p, m, v = O.adamw_step(ref_p, clipped, m, v, step)
+        for i, p in enumerate(ps):
+            torch.testing.assert_close(p.detach().cpu(), ref_p[str(i)], rtol=1e-5, atol=1e-6)

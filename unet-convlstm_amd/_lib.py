@@ -1,0 +1,137 @@
+"""ctypes binding of libuclstm.so (include/uclstm.h).
+
+This is the only place the shared library is loaded.  There is no fallback: if the library is
+missing or lacks a symbol the import of the product package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libuclstm.so")
+HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
+
+ABI_VERSION = 1
+EPI_STORE, EPI_LSTM = 0, 1
+NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
+KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
+
+_ERRORS = {-1: "bad argument (shape/alignment/null contract)", -2: "kernel launch failed", -3: "no gfx950 device"}
+
+
+class UclstmError(RuntimeError):
+    pass
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32),
+                ("offY", C.c_int32), ("offX", C.c_int32)]
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n_begin", C.c_int32), ("n_end", C.c_int32), ("C", C.c_int32),
+                ("c_off", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32), ("scale", C.c_int32),
+                ("oy", C.c_int32), ("ox", C.c_int32)]
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("groups", C.c_int32),
+                ("ktap", C.c_int32), ("scale", C.c_int32), ("pad", C.c_int32), ("nsrc", C.c_int32),
+                ("src", Src * 2),
+                ("wp", C.c_void_p), ("N", C.c_int32), ("Ktot", C.c_int32),
+                ("bias", C.c_void_p), ("col_scale", C.c_void_p), ("col_shift", C.c_void_p),
+                ("relu", C.c_int32), ("epi", C.c_int32),
+                ("nseg", C.c_int32), ("seg", Seg * 4),
+                ("stats", C.c_void_p),
+                ("Hd_p", C.c_int32), ("c_prev", C.c_void_p), ("c_out", C.c_void_p), ("h_out", C.c_void_p),
+                ("gates_out", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("ktap", C.c_int32), ("scale", C.c_int32), ("pad", C.c_int32), ("nsrc", C.c_int32),
+                ("src", Src * 2),
+                ("N", C.c_int32), ("Ktot", C.c_int32),
+                ("nseg", C.c_int32), ("seg", Seg * 4),
+                ("dwp", C.c_void_p), ("splits", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Ktot", C.c_int32), ("taps", C.c_int32), ("nsrc", C.c_int32),
+                ("kseg", C.c_int32 * 2), ("cvalid", C.c_int32 * 2), ("choff", C.c_int32 * 2),
+                ("n_mode", C.c_int32), ("n_valid", C.c_int32), ("n_cp", C.c_int32),
+                ("k_mode", C.c_int32), ("k_hdp", C.c_int32), ("k_hd", C.c_int32),
+                ("tap_flip", C.c_int32),
+                ("stride_n", C.c_int64), ("stride_k", C.c_int64), ("stride_tap", C.c_int64),
+                ("stride_ntap", C.c_int64)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype int32 unless listed in _RESTYPES)
+_PROTOS = {
+    "uclstm_igemm_tiles_per_group": [_I, _I, _I, _I],
+    "uclstm_igemm_fwd": [C.POINTER(IgemmDesc), _P],
+    "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
+    "uclstm_pack_weights": [C.POINTER(PackDesc), _P, _P, _P],
+    "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _P, _I, _P],
+    "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],
+    "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    "uclstm_bn_apply_relu": [_P, _P, _P, _P, _L, _L, _I, _P],
+    "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
+    "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
+    "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "uclstm_maxpool2_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P],
+    "uclstm_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],
+    "uclstm_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "uclstm_nchw_grad_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "uclstm_im2col3x3_first": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],
+    "uclstm_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "uclstm_nhwc_to_nchw_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "uclstm_outconv_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "uclstm_outconv_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "uclstm_colsum": [_P, _P, _L, _I, _P],
+    "uclstm_loss_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "uclstm_loss_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "uclstm_sumsq": [_P, _L, _P, _P],
+    "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
+    "uclstm_abi_version": [],
+    "uclstm_build_arch": [],
+}
+_RESTYPES = {"uclstm_build_arch": C.c_char_p}
+
+
+def header_symbols() -> list[str]:
+    """Every function name declared in include/uclstm.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(uclstm_[a-z0-9_]+)\s*\(", text)))
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise UclstmError(
+            f"{LIB_PATH} is missing: build it with `python unet-convlstm_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for this package.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise UclstmError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int32)
+    if lib.uclstm_abi_version() != ABI_VERSION:
+        raise UclstmError("libuclstm.so ABI version mismatch; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise UclstmError(f"{what}: {_ERRORS.get(rc, 'error')} (code {rc})")

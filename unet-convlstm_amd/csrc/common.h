@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 kernels of libuclstm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uclstm.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define UCLSTM_WAVE 64
+
+#define UCLSTM_CHECK_LAUNCH()                                   \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return UCLSTM_E_LAUNCH;          \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f32_to_bf16(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32: RNE, NaN preserved
+
+// 8 bf16 <-> 8 floats through one 16-byte register quad
+union Pack16 {
+    uint4 u;
+    bf16x8 v;
+    bf16 e[8];
+};
+union Pack8 {
+    uint2 u;
+    bf16x4 v;
+    bf16 e[4];
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 - 2/(e^{2x}+1): saturates correctly to +-1 for large |x|
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int32_t round_up32(int32_t a, int32_t b) { return (a + b - 1) / b * b; }
+
+// Bijective XCD-aware remap of a 1-D grid (guide T1): blocks that share an XCD (b % 8) get a
+// contiguous run of logical ids, so neighbouring tiles (which share a weight panel) hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// Division of a 31-bit dividend by a runtime constant: q = umulhi(m, magic) >> shift (Granlund-Montgomery
+// round-up form; exact for every m < 2^31).  magic == 0 encodes d == 1.
+struct FastDiv {
+    uint32_t magic;
+    uint32_t shift;
+    uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) {
+        f.magic = 0;
+        f.shift = 0;
+        return f;
+    }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned s = 31 + l;
+    f.magic = (uint32_t)(((1ull << s) + d - 1) / d);
+    f.shift = s - 32;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t m, const FastDiv& f) {
+    return f.magic ? (__umulhi(m, f.magic) >> f.shift) : m;
+}

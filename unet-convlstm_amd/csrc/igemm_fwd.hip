@@ -1,0 +1,351 @@
+// Implicit-GEMM convolution on MFMA (gfx950), pixel-major forward family.
+//
+//   D[n][m] = sum_k Wp[n][k] * A[m][k]        n = panel row (output channel), m = output pixel
+//
+// A is never materialised: for K-step (tap, source, 64-channel slice) row m of A is the 128
+// contiguous bytes src[s][img][y*scale+dy-pad][x*scale+dx-pad][c0:c0+64] (zeros outside the
+// image), so torch.cat([x,h]) / cat([skip,up]) / F.pad of the reference (train/unet.py:28,
+// :95-98) never exist in memory.  Tile 128 panel rows x 128 pixels x 64 K, 4 waves (2x2), each
+// wave 64x64 as 4x4 v_mfma_f32_16x16x32_bf16 with the PANEL as the MFMA A operand: a lane then
+// owns 4 consecutive output channels of one pixel, which makes the LSTM gate quadruple
+// (i,f,g,o of one hidden channel = 4 M-subtiles of a wave) lane-local and lets the epilogue
+// pack 8-byte channel runs.  LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte
+// chunk (conflict-free ds_read_b128, guide T2).  Global->register->LDS staging is split
+// (issue loads for step s+1 before the MFMAs of step s, write LDS after; guide T14), one
+// barrier per K-step, two LDS stages.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;   // pixels per tile
+constexpr int BN = 128;   // panel rows per tile
+constexpr int BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // X tile then W tile
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB
+constexpr int OT_PITCH = BN * 2 + 16;            // staged output tile: bytes per pixel row
+
+struct Derived {
+    int Mg;          // pixels per statistic group
+    int tpg;         // M tiles per group
+    int n_mtiles;    // groups * tpg
+    int n_ntiles;
+    int kseg0, kseg1;
+    int ksteps;      // total K steps
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1;      // wave position along panel rows
+    const int wpx = wave & 1;      // wave position along pixels
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+
+    const int lid = xcd_remap(blockIdx.x, dv.n_mtiles * dv.n_ntiles);
+    const int nt = lid / dv.n_mtiles;
+    const int mt = lid - nt * dv.n_mtiles;
+    const int g = mt / dv.tpg;
+    const int tile = mt - g * dv.tpg;
+    const int m_local0 = tile * BM;
+    const long m0 = (long)g * dv.Mg + m_local0;
+    const int rows_valid = min(BM, dv.Mg - m_local0);
+    const int n0 = nt * BN;
+    const int HW = d.H * d.W;
+
+    // ---- rows this thread stages: lrow0 + 32*i, 16-byte chunk lchunk ----
+    const int lchunk = tid & 7;
+    const int lrow0 = tid >> 3;
+    int pn[4], py[4], px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lrow0 + 32 * i;
+        if (r < rows_valid) {
+            const long m = m0 + r;
+            const int img = (int)(m / HW);
+            const int rem = (int)(m - (long)img * HW);
+            const int y = rem / d.W;
+            pn[i] = img;
+            py[i] = y;
+            px[i] = rem - y * d.W;
+        } else {
+            pn[i] = 0;
+            py[i] = -(1 << 20);   // every tap lands outside the image -> zero fill
+            px[i] = 0;
+        }
+    }
+    const int sw = (lchunk ^ (lrow0 & 7)) << 4;   // swizzled chunk byte offset (row & 7 is i-invariant)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // K-step cursor of the NEXT load
+    int tap = 0, s = 0, c0 = 0, kstep = 0;
+    uint4 ra[4], rb[4];
+
+    auto issue_loads = [&]() {
+        const uclstm_src S = d.src[s];
+        const int tdy = tap / d.ktap;
+        const int dy = tdy - d.pad - S.offY;
+        const int dx = (tap - tdy * d.ktap) - d.pad - S.offX;
+        const int c = c0 + lchunk * 8;
+        const bool cvalid = c < S.C;
+        const bf16* base = (const bf16*)S.ptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ys = py[i] * d.scale + dy;
+            const int xs = px[i] * d.scale + dx;
+            const bool ok = cvalid && (unsigned)ys < (unsigned)S.Hs && (unsigned)xs < (unsigned)S.Ws;
+            const bf16* p = base + (((long)pn[i] * S.Hs + ys) * S.Ws + xs) * (long)S.C + c;
+            ra[i] = ok ? *(const uint4*)p : make_uint4(0u, 0u, 0u, 0u);
+        }
+        const bf16* wbase = (const bf16*)d.wp + (long)kstep * BK + lchunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nrow = n0 + lrow0 + 32 * i;
+            rb[i] = (nrow < d.N) ? *(const uint4*)(wbase + (long)nrow * d.Ktot) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        // advance cursor
+        ++kstep;
+        c0 += BK;
+        if (c0 >= (s == 0 ? dv.kseg0 : dv.kseg1)) {
+            c0 = 0;
+            if (++s == d.nsrc) {
+                s = 0;
+                ++tap;
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char* X = smem + buf * STAGE_BYTES;
+        unsigned char* Wt = X + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (lrow0 + 32 * i) * 128 + sw;
+            *(uint4*)(X + off) = ra[i];
+            *(uint4*)(Wt + off) = rb[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* X = smem + buf * STAGE_BYTES;
+        const unsigned char* Wt = X + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int choff = ((kk * 4 + lq) ^ (l15 & 7)) << 4;
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop ----
+    issue_loads();
+    stage_store(0);
+    __syncthreads();
+    for (int step = 0; step < dv.ksteps; ++step) {
+        const bool more = step + 1 < dv.ksteps;
+        if (more) issue_loads();
+        compute(step & 1);
+        if (more) stage_store((step + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    if constexpr (EPI == UCLSTM_EPI_LSTM) {
+        const int hc = ((n0 >> 6) + wc) * 16 + lq * 4;     // first of this lane's 4 hidden channels
+        if (hc < d.Hd_p) {
+            float bg[4][4];
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) {
+                const int nb = n0 + wc * 64 + gate * 16 + lq * 4;
+                if (d.bias) {
+                    const float4 t = *(const float4*)(d.bias + nb);
+                    bg[gate][0] = t.x; bg[gate][1] = t.y; bg[gate][2] = t.z; bg[gate][3] = t.w;
+                } else {
+                    bg[gate][0] = bg[gate][1] = bg[gate][2] = bg[gate][3] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int prow = wpx * 64 + b * 16 + l15;
+                if (prow < rows_valid) {
+                    const long pix = m0 + prow;
+                    float cp[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (d.c_prev) {
+                        const float4 t = *(const float4*)(d.c_prev + pix * d.Hd_p + hc);
+                        cp[0] = t.x; cp[1] = t.y; cp[2] = t.z; cp[3] = t.w;
+                    }
+                    float cn[4];
+                    Pack8 hi, gi, gf, gg, go;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float vi = fast_sigmoid(acc[0][b][r] + bg[0][r]);
+                        const float vf = fast_sigmoid(acc[1][b][r] + bg[1][r]);
+                        const float vg = fast_tanh(acc[2][b][r] + bg[2][r]);
+                        const float vo = fast_sigmoid(acc[3][b][r] + bg[3][r]);
+                        cn[r] = vf * cp[r] + vi * vg;                 // train/unet.py:34
+                        hi.e[r] = f32_to_bf16(vo * fast_tanh(cn[r])); // train/unet.py:35
+                        gi.e[r] = f32_to_bf16(vi);
+                        gf.e[r] = f32_to_bf16(vf);
+                        gg.e[r] = f32_to_bf16(vg);
+                        go.e[r] = f32_to_bf16(vo);
+                    }
+                    *(float4*)(d.c_out + pix * d.Hd_p + hc) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+                    *(uint2*)((bf16*)d.h_out + pix * d.Hd_p + hc) = hi.u;
+                    if (d.gates_out) {
+                        bf16* gp = (bf16*)d.gates_out + pix * 4 * d.Hd_p + hc;
+                        *(uint2*)(gp) = gi.u;
+                        *(uint2*)(gp + d.Hd_p) = gf.u;
+                        *(uint2*)(gp + 2 * d.Hd_p) = gg.u;
+                        *(uint2*)(gp + 3 * d.Hd_p) = go.u;
+                    }
+                }
+            }
+        }
+    } else {
+        unsigned char* Ot = smem;    // [128 pixels][OT_PITCH]; all K-loop LDS reads retired by the last barrier
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int col = wc * 64 + a * 16 + lq * 4;
+            const int n = n0 + col;
+            float bs[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < d.N) {
+                if (d.bias) { const float4 t = *(const float4*)(d.bias + n); bs[0] = t.x; bs[1] = t.y; bs[2] = t.z; bs[3] = t.w; }
+                if (d.col_scale) { const float4 t = *(const float4*)(d.col_scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+                if (d.col_shift) { const float4 t = *(const float4*)(d.col_shift + n); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int prow = wpx * 64 + b * 16 + l15;
+                Pack8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = (acc[a][b][r] + bs[r]) * sc[r] + sh[r];
+                    if (d.relu) v = fmaxf(v, 0.f);
+                    o.e[r] = f32_to_bf16(v);
+                }
+                *(uint2*)(Ot + prow * OT_PITCH + col * 2) = o.u;
+            }
+        }
+        __syncthreads();
+
+        if (d.stats && tid < BN) {
+            const int n = n0 + tid;
+            if (n < d.N) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < rows_valid; ++r) {
+                    const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + tid * 2));
+                    s1 += v;
+                    s2 += v * v;
+                }
+                float* sp = d.stats + ((long)mt * d.N + n) * 2;
+                sp[0] = s1;
+                sp[1] = s2;
+            }
+        }
+
+        for (int q = tid; q < BM * (BN / 8); q += 256) {
+            const int r = q >> 4;
+            const int cc = q & 15;
+            const int n = n0 + cc * 8;
+            if (r >= rows_valid || n >= d.N) continue;
+            const long m = m0 + r;
+            const int img = (int)(m / HW);
+            const int rem = (int)(m - (long)img * HW);
+            const int y = rem / d.W;
+            const int x = rem - y * d.W;
+#pragma unroll
+            for (int si = 0; si < 4; ++si) {
+                if (si < d.nseg && n >= d.seg[si].n_begin && n < d.seg[si].n_end) {
+                    const uclstm_seg sg = d.seg[si];
+                    const int yd = y * sg.scale + sg.oy;
+                    const int xd = x * sg.scale + sg.ox;
+                    if ((unsigned)yd < (unsigned)sg.Hd && (unsigned)xd < (unsigned)sg.Wd) {
+                        bf16* dst = (bf16*)sg.ptr + (((long)img * sg.Hd + yd) * sg.Wd + xd) * (long)sg.C + sg.c_off + (n - sg.n_begin);
+                        *(uint4*)dst = *(const uint4*)(Ot + r * OT_PITCH + cc * 16);
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool src_ok(const uclstm_src& s) {
+    return s.ptr && s.C > 0 && (s.C % 8) == 0 && s.Hs > 0 && s.Ws > 0 && ((uintptr_t)s.ptr % 16) == 0;
+}
+
+}  // namespace
+
+extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups) {
+    if (groups <= 0 || n_img <= 0 || n_img % groups) return UCLSTM_E_BADARG;
+    const int64_t mg = (int64_t)(n_img / groups) * H * W;
+    return (int32_t)((mg + BM - 1) / BM);
+}
+
+extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
+    if (!dp) return UCLSTM_E_BADARG;
+    const uclstm_igemm_desc& d = *dp;
+    if (d.n_img <= 0 || d.H <= 0 || d.W <= 0 || d.groups <= 0 || d.n_img % d.groups) return UCLSTM_E_BADARG;
+    if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
+    if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
+    for (int s = 0; s < d.nsrc; ++s)
+        if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;
+    Derived dv;
+    dv.kseg0 = round_up32(d.src[0].C, BK);
+    dv.kseg1 = d.nsrc > 1 ? round_up32(d.src[1].C, BK) : 0;
+    const int taps = d.ktap * d.ktap;
+    if (d.Ktot != taps * (dv.kseg0 + dv.kseg1)) return UCLSTM_E_BADARG;
+    dv.ksteps = d.Ktot / BK;
+    const int64_t mg = (int64_t)(d.n_img / d.groups) * d.H * d.W;
+    if (mg * d.groups > (int64_t)1 << 40) return UCLSTM_E_BADARG;
+    dv.Mg = (int)mg;
+    dv.tpg = (int)((mg + BM - 1) / BM);
+    dv.n_mtiles = d.groups * dv.tpg;
+    dv.n_ntiles = (d.N + BN - 1) / BN;
+    const int64_t nblk = (int64_t)dv.n_mtiles * dv.n_ntiles;
+    if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
+
+    if (d.epi == UCLSTM_EPI_LSTM) {
+        if (d.Hd_p <= 0 || (d.Hd_p % 8) || (d.N % 64) || d.N != 64 * ((d.Hd_p + 15) / 16)) return UCLSTM_E_BADARG;
+        if (!d.c_out || !d.h_out) return UCLSTM_E_BADARG;
+    } else if (d.epi == UCLSTM_EPI_STORE) {
+        if (d.nseg < 1 || d.nseg > 4) return UCLSTM_E_BADARG;
+        for (int i = 0; i < d.nseg; ++i) {
+            const uclstm_seg& sg = d.seg[i];
+            if (!sg.ptr || (sg.n_begin % 8) || (sg.n_end % 8) || sg.n_end <= sg.n_begin || (sg.C % 8) || (sg.c_off % 8) ||
+                sg.c_off + (sg.n_end - sg.n_begin) > sg.C || sg.Hd <= 0 || sg.Wd <= 0 || sg.scale < 1 ||
+                ((uintptr_t)sg.ptr % 16))
+                return UCLSTM_E_BADARG;
+        }
+    } else {
+        return UCLSTM_E_BADARG;
+    }
+
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<UCLSTM_EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<UCLSTM_EPI_LSTM>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d.epi == UCLSTM_EPI_LSTM)
+        hipLaunchKernelGGL(igemm_fwd_kernel<UCLSTM_EPI_LSTM>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
+    else
+        hipLaunchKernelGGL(igemm_fwd_kernel<UCLSTM_EPI_STORE>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}

@@ -1,0 +1,752 @@
+// HBM-bound kernels around the MFMA GEMMs: BatchNorm(+ReLU) finalize/apply/backward, MaxPool2d(2),
+// the ConvLSTM backward point-wise part, layout conversion at the module boundary, OutConv 1x1 and
+// column sums.  All move 16 bytes (8 bf16 channels) per lane per access on NHWC tensors; reductions
+// over pixels keep a fixed channel chunk per thread, reduce across the block in LDS and finish with
+// one f32 atomic per (block, channel).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
+    Pack16 p;
+    p.u = u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(p.e[i]);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    Pack16 p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.e[i] = f32_to_bf16(f[i]);
+    return p.u;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void store8f(float* p, const float (&f)[8]) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+int ew_grid(int64_t items) {
+    int64_t b = (items + NT - 1) / NT;
+    if (b > 256 * 8) b = 256 * 8;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm finalize
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C, double inv_cnt,
+                                   double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ rstd_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    const bool real = c < C;
+    const float ga = real ? gamma[c] : 0.f, be = real ? beta[c] : 0.f;
+    float rm = real ? rmean[c] : 0.f, rv = real ? rvar[c] : 1.f;
+    for (int g = 0; g < groups; ++g) {
+        float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+        if (real) {
+            if (stats) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t < tpg; ++t) {
+                    const float* sp = stats + (((long)g * tpg + t) * Cp + c) * 2;
+                    s1 += sp[0];
+                    s2 += sp[1];
+                }
+                const double m = s1 * inv_cnt;
+                double var = s2 * inv_cnt - m * m;
+                var = var < 0.0 ? 0.0 : var;
+                mu = (float)m;
+                rs = (float)(1.0 / sqrt(var + (double)eps));
+                // running stats: one momentum step per group, in group order (train/unet.py:179,:196)
+                rm = (1.f - momentum) * rm + momentum * mu;
+                rv = (1.f - momentum) * rv + momentum * (float)(var * unbias);
+            } else {
+                mu = rm;
+                rs = 1.0f / sqrtf(rv + eps);
+            }
+            sc = ga * rs;
+            sh = be - mu * sc;
+        }
+        const long o = (long)g * Cp + c;
+        scale[o] = sc;
+        shift[o] = sh;
+        if (mean_o) mean_o[o] = mu;
+        if (rstd_o) rstd_o[o] = rs;
+    }
+    if (real && stats) {
+        rmean[c] = rm;
+        rvar[c] = rv;
+    }
+}
+
+// a = relu(z*scale + shift)
+__global__ void bn_apply_relu_kernel(const uint4* __restrict__ z, uint4* __restrict__ a, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, int64_t chunks, FastDiv dcpc, FastDiv dppg, int Cp) {
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - pix * dcpc.d;
+        const uint32_t g = fdiv(pix, dppg);
+        const long so = (long)g * Cp + cc * 8;
+        float v[8], sc[8], sh[8];
+        unpack8(z[idx], v);
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+        a[idx] = pack8(v);
+    }
+}
+
+// Column-reduction geometry: a block of NT threads covers `rows` pixel rows x cpc chunk columns per sweep.
+struct ColGeom {
+    int cpc;       // 16-byte chunks per pixel
+    int rows;      // pixel rows per sweep = NT / cpc (>= 1)
+    int active;    // rows * cpc
+};
+static ColGeom col_geom(int Cp) {
+    ColGeom g;
+    g.cpc = Cp / 8;
+    g.rows = NT / g.cpc;
+    if (g.rows < 1) g.rows = 1;
+    g.active = g.rows * g.cpc;
+    return g;
+}
+
+// sums[g][c][0..1] += (sum g_, sum g_*xhat)
+__global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ sums, int64_t ppg, int Cp, ColGeom cg,
+                                     int blocks_per_group, int64_t pix_per_block) {
+    extern __shared__ float red[];     // [rows][cpc*16]
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
+    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    // thread t handles chunk column t % cpc of rows t / cpc + k*rows; columns beyond 256 threads loop
+    for (int cbase = 0; cbase < cg.cpc; cbase += NT) {
+        const int cc = cbase + (cg.cpc >= NT ? threadIdx.x : threadIdx.x % cg.cpc);
+        const int prow = cg.cpc >= NT ? 0 : threadIdx.x / cg.cpc;
+        const bool act = (cg.cpc >= NT) ? (cc < cg.cpc) : (threadIdx.x < cg.active);
+        float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            const long so = (long)g * Cp + cc * 8;
+            float sc[8], sh[8], mu[8], rs[8];
+            load8f(scale + so, sc);
+            load8f(shift + so, sh);
+            load8f(mean + so, mu);
+            load8f(rstd + so, rs);
+            for (int64_t p = p0 + prow; p < p1; p += cg.rows) {
+                float zv[8], gv[8];
+                unpack8(z[p * cg.cpc + cc], zv);
+                unpack8(da[p * cg.cpc + cc], gv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float gg = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
+                    s1[i] += gg;
+                    s2[i] += gg * (zv[i] - mu[i]) * rs[i];
+                }
+            }
+        }
+        const int width = min(cg.cpc, NT) * 16;
+        if (act) {
+            float* r = red + prow * width + (cc - cbase) * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                r[i * 2] = s1[i];
+                r[i * 2 + 1] = s2[i];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < width; j += NT) {
+            float t = 0.f;
+            for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+            const int ch = (cbase * 8) + (j >> 1);
+            if (ch < Cp) atomicAdd(sums + ((long)g * Cp + ch) * 2 + (j & 1), t);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ sums, uint4* __restrict__ dz,
+                                    int64_t chunks, FastDiv dcpc, FastDiv dppg, int Cp, float inv_n) {
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - pix * dcpc.d;
+        const uint32_t g = fdiv(pix, dppg);
+        const long so = (long)g * Cp + cc * 8;
+        float zv[8], gv[8], sc[8], sh[8], mu[8], rs[8], o[8];
+        unpack8(z[idx], zv);
+        unpack8(da[idx], gv);
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gg = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
+            const float xh = (zv[i] - mu[i]) * rs[i];
+            const float s1 = sums[(so + i) * 2], s2 = sums[(so + i) * 2 + 1];
+            o[i] = sc[i] * (gg - s1 * inv_n - xh * s2 * inv_n);
+        }
+        dz[idx] = pack8(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2)
+// ---------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const uint4* __restrict__ a, uint4* __restrict__ p, int64_t chunks, FastDiv dcpc, FastDiv dWo,
+                                   FastDiv dHo, int H, int W) {
+    const int cpc = dcpc.d, Wo = dWo.d, Ho = dHo.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t opix = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - opix * cpc;
+        const uint32_t t = fdiv(opix, dWo);
+        const uint32_t xo = opix - t * Wo;
+        const uint32_t img = fdiv(t, dHo);
+        const uint32_t yo = t - img * Ho;
+        const int64_t base = (((int64_t)img * H + 2 * yo) * W + 2 * xo) * cpc + cc;
+        float v0[8], v1[8], v2[8], v3[8], o[8];
+        unpack8(a[base], v0);
+        unpack8(a[base + cpc], v1);
+        unpack8(a[base + (int64_t)W * cpc], v2);
+        unpack8(a[base + (int64_t)W * cpc + cpc], v3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaxf(fmaxf(v0[i], v1[i]), fmaxf(v2[i], v3[i]));
+        p[idx] = pack8(o);
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __restrict__ dp, uint4* __restrict__ da, int64_t chunks,
+                                   FastDiv dcpc, FastDiv dWo, FastDiv dHo, int H, int W) {
+    const int cpc = dcpc.d, Wo = dWo.d, Ho = dHo.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t opix = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - opix * cpc;
+        const uint32_t t = fdiv(opix, dWo);
+        const uint32_t xo = opix - t * Wo;
+        const uint32_t img = fdiv(t, dHo);
+        const uint32_t yo = t - img * Ho;
+        const int64_t b0 = (((int64_t)img * H + 2 * yo) * W + 2 * xo) * cpc + cc;
+        const int64_t offs[4] = {0, cpc, (int64_t)W * cpc, (int64_t)W * cpc + cpc};
+        float v[4][8], g[8], o[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unpack8(a[b0 + offs[k]], v[k]);
+        unpack8(dp[idx], g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // first maximum in scan order (0,0),(0,1),(1,0),(1,1): strict '>' keeps the earlier one
+            int best = 0;
+            float m = v[0][i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][i] > m) {
+                    m = v[k][i];
+                    best = k;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][i] = (k == best) ? g[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) da[b0 + offs[k]] = pack8(o[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM backward, point-wise part
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                                   const uint4* __restrict__ dh_a, const uint4* __restrict__ dh_b, float* __restrict__ dc_io,
+                                   int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
+    const int cpc = dcpc.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - pix * cpc;
+        const int64_t gb = (int64_t)pix * 4 * cpc + cc;
+        float gi[8], gf[8], gg[8], go[8], cp[8], cn[8], dh[8], dc[8];
+        unpack8(gates[gb], gi);
+        unpack8(gates[gb + cpc], gf);
+        unpack8(gates[gb + 2 * cpc], gg);
+        unpack8(gates[gb + 3 * cpc], go);
+        if (c_prev) load8f(c_prev + idx * 8, cp);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cp[i] = 0.f;
+        }
+        load8f(c_new + idx * 8, cn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dh[i] = 0.f;
+        if (dh_a) unpack8(dh_a[idx], dh);
+        if (dh_b) {
+            float t[8];
+            unpack8(dh_b[idx], t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dh[i] += t[i];
+        }
+        if (dc_is_zero) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dc[i] = 0.f;
+        } else {
+            load8f(dc_io + idx * 8, dc);
+        }
+        float di[8], df[8], dg[8], dO[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float tc = fast_tanh(cn[i]);
+            dO[i] = dh[i] * tc * go[i] * (1.f - go[i]);
+            const float dct = dc[i] + dh[i] * go[i] * (1.f - tc * tc);
+            df[i] = dct * cp[i] * gf[i] * (1.f - gf[i]);
+            di[i] = dct * gg[i] * gi[i] * (1.f - gi[i]);
+            dg[i] = dct * gi[i] * (1.f - gg[i] * gg[i]);
+            dc[i] = dct * gf[i];
+        }
+        dgates[gb] = pack8(di);
+        dgates[gb + cpc] = pack8(df);
+        dgates[gb + 2 * cpc] = pack8(dg);
+        dgates[gb + 3 * cpc] = pack8(dO);
+        store8f(dc_io + idx * 8, dc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout conversion (module boundary)
+// ---------------------------------------------------------------------------------------------
+// thread <-> (chunk column, pixel) with the pixel fastest: NCHW reads are coalesced.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, uint4* __restrict__ out, int64_t items, int C, int cpc, FastDiv dHW,
+                                    FastDiv dcpc, FastDiv dinner, int64_t inner_stride, int64_t outer_stride) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        // idx = (img*cpc + cc)*HW + pix
+        const uint32_t t = fdiv((uint32_t)idx, dHW);
+        const uint32_t pix = (uint32_t)idx - t * HW;
+        const uint32_t img = fdiv(t, dcpc);
+        const uint32_t cc = t - img * cpc;
+        const uint32_t o = fdiv(img, dinner);
+        const uint32_t in = img - o * dinner.d;
+        const float* src = x + (int64_t)in * outer_stride + (int64_t)o * inner_stride;   // image i = o*inner + in reads [in][o]
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cc * 8 + i;
+            v[i] = c < C ? src[(int64_t)c * HW + pix] : 0.f;
+        }
+        out[((int64_t)img * HW + pix) * cpc + cc] = pack8(v);
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const uint4* __restrict__ a, float* __restrict__ out, int64_t items, int C, int cpc, FastDiv dHW,
+                                    FastDiv dcpc) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t t = fdiv((uint32_t)idx, dHW);
+        const uint32_t pix = (uint32_t)idx - t * HW;
+        const uint32_t img = fdiv(t, dcpc);
+        const uint32_t cc = t - img * cpc;
+        float v[8];
+        unpack8(a[((int64_t)img * HW + pix) * cpc + cc], v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cc * 8 + i;
+            if (c < C) out[((int64_t)img * C + c) * HW + pix] = v[i];
+        }
+    }
+}
+
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t items, int C, int Cp, FastDiv dHW,
+                                        FastDiv dCp) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        // idx = (img*Cp + c)*HW + pix
+        const uint32_t t = fdiv((uint32_t)idx, dHW);
+        const uint32_t pix = (uint32_t)idx - t * HW;
+        const uint32_t img = fdiv(t, dCp);
+        const uint32_t c = t - img * Cp;
+        out[((int64_t)img * HW + pix) * Cp + c] = (int)c < C ? x[((int64_t)img * C + c) * HW + pix] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t items, int C, int Cp, FastDiv dHW,
+                                        FastDiv dC) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        // idx = (img*C + c)*HW + pix
+        const uint32_t t = fdiv((uint32_t)idx, dHW);
+        const uint32_t pix = (uint32_t)idx - t * HW;
+        const uint32_t img = fdiv(t, dC);
+        const uint32_t c = t - img * C;
+        out[idx] = a[((int64_t)img * HW + pix) * Cp + c];
+    }
+}
+
+__global__ void im2col_first_kernel(const float* __restrict__ x, uint4* __restrict__ out, int64_t items, int C, int kpc, int H, int W,
+                                    FastDiv dHW, FastDiv dW, FastDiv dkpc, FastDiv dinner, FastDiv dC, int64_t inner_stride,
+                                    int64_t outer_stride) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        // idx = (img*kpc + kc)*HW + pix
+        const uint32_t t = fdiv((uint32_t)idx, dHW);
+        const uint32_t pix = (uint32_t)idx - t * HW;
+        const uint32_t img = fdiv(t, dkpc);
+        const uint32_t kc = t - img * kpc;
+        const int y = (int)fdiv(pix, dW);
+        const int xx = (int)pix - y * W;
+        const uint32_t o = fdiv(img, dinner);
+        const uint32_t in = img - o * dinner.d;
+        const float* src = x + (int64_t)in * outer_stride + (int64_t)o * inner_stride;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t k = kc * 8 + i;
+            const uint32_t tap = fdiv(k, dC);
+            const int c = (int)(k - tap * C);
+            const int ys = y + (int)(tap / 3) - 1, xs = xx + (int)(tap % 3) - 1;
+            v[i] = (tap < 9 && (unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W) ? src[(int64_t)c * HW + ys * W + xs] : 0.f;
+        }
+        out[((int64_t)img * HW + pix) * kpc + kc] = pack8(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// OutConv 1x1
+// ---------------------------------------------------------------------------------------------
+__global__ void outconv_fwd_kernel(const uint4* __restrict__ a, const float* __restrict__ w, const float* __restrict__ b,
+                                   float* __restrict__ y, int64_t pixels, FastDiv dHW, int cpc, int C, int Co) {
+    const int HW = dHW.d;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * NT) {
+        const uint32_t img = fdiv((uint32_t)p, dHW);
+        const uint32_t pix = (uint32_t)p - img * HW;
+        for (int co = 0; co < Co; ++co) {
+            float acc = b ? b[co] : 0.f;
+            for (int cc = 0; cc < cpc; ++cc) {
+                float v[8];
+                unpack8(a[p * cpc + cc], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = cc * 8 + i;
+                    if (c < C) acc += v[i] * w[co * C + c];
+                }
+            }
+            y[((int64_t)img * Co + co) * HW + pix] = acc;
+        }
+    }
+}
+
+__global__ void outconv_bwd_da_kernel(const float* __restrict__ w, const float* __restrict__ dy, uint4* __restrict__ da, int64_t chunks,
+                                      FastDiv dcpc, FastDiv dHW, int C, int Co) {
+    const int cpc = dcpc.d, HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t p = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - p * cpc;
+        const uint32_t img = fdiv(p, dHW);
+        const uint32_t pix = p - img * HW;
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int co = 0; co < Co; ++co) {
+            const float g = dy[((int64_t)img * Co + co) * HW + pix];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cc * 8 + i;
+                if (c < C) o[i] += g * w[co * C + c];
+            }
+        }
+        da[idx] = pack8(o);
+    }
+}
+
+// dw[co][c] += sum_p dy[p][co]*a[p][c]; db[co] += sum_p dy[p][co]   (one co per blockIdx.y)
+__global__ void outconv_bwd_dw_kernel(const uint4* __restrict__ a, const float* __restrict__ dy, float* __restrict__ dw,
+                                      float* __restrict__ db, int64_t pixels, FastDiv dHW, ColGeom cg, int C, int Co,
+                                      int64_t pix_per_block) {
+    extern __shared__ float red[];   // [rows][cpc*8 + 1]
+    const int co = blockIdx.y;
+    const int HW = dHW.d;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(pixels, p0 + pix_per_block);
+    const int width = cg.cpc * 8 + 1;
+    for (int j = threadIdx.x; j < cg.rows * width; j += NT) red[j] = 0.f;
+    __syncthreads();
+    if ((int)threadIdx.x < cg.active) {
+        const int cc = threadIdx.x % cg.cpc, prow = threadIdx.x / cg.cpc;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
+        for (int64_t p = p0 + prow; p < p1; p += cg.rows) {
+            const uint32_t img = fdiv((uint32_t)p, dHW);
+            const uint32_t pix = (uint32_t)p - img * HW;
+            const float g = dy[((int64_t)img * Co + co) * HW + pix];
+            float v[8];
+            unpack8(a[p * cg.cpc + cc], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += g * v[i];
+            sb += g;
+        }
+        float* r = red + prow * width;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[cc * 8 + i] = s[i];
+        if (cc == 0) r[cg.cpc * 8] = sb;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < width; j += NT) {
+        float t = 0.f;
+        for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+        if (j < cg.cpc * 8) {
+            if (j < C) atomicAdd(dw + co * C + j, t);
+        } else {
+            atomicAdd(db + co, t);
+        }
+    }
+}
+
+__global__ void colsum_kernel(const uint4* __restrict__ a, float* __restrict__ out, int64_t pixels, ColGeom cg, int Cp,
+                              int64_t pix_per_block) {
+    extern __shared__ float red[];   // [rows][min(cpc,NT)*8]
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(pixels, p0 + pix_per_block);
+    for (int cbase = 0; cbase < cg.cpc; cbase += NT) {
+        const int cc = cbase + (cg.cpc >= NT ? threadIdx.x : threadIdx.x % cg.cpc);
+        const int prow = cg.cpc >= NT ? 0 : threadIdx.x / cg.cpc;
+        const bool act = (cg.cpc >= NT) ? (cc < cg.cpc) : ((int)threadIdx.x < cg.active);
+        const int width = min(cg.cpc, NT) * 8;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            for (int64_t p = p0 + prow; p < p1; p += cg.rows) {
+                float v[8];
+                unpack8(a[p * cg.cpc + cc], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += v[i];
+            }
+            float* r = red + prow * width + (cc - cbase) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = s[i];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < width; j += NT) {
+            float t = 0.f;
+            for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+            const int ch = cbase * 8 + j;
+            if (ch < Cp) atomicAdd(out + ch, t);
+        }
+        __syncthreads();
+    }
+}
+
+bool aligned16(const void* p) { return p && ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int32_t uclstm_bn_finalize(const float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
+                                      int64_t count_per_group, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                                      float* rstd, void* stream) {
+    if (groups <= 0 || Cp <= 0 || C <= 0 || C > Cp || !gamma || !beta || !running_mean || !running_var || !scale || !shift)
+        return UCLSTM_E_BADARG;
+    if (stats && (tiles_per_group <= 0 || count_per_group <= 0)) return UCLSTM_E_BADARG;
+    const double inv = stats ? 1.0 / (double)count_per_group : 0.0;
+    const double unb = (stats && count_per_group > 1) ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C,
+                       inv, unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift, int64_t pixels,
+                                        int64_t pixels_per_group, int32_t Cp, void* stream) {
+    if (!aligned16(z) || !aligned16(a) || !scale || !shift || pixels <= 0 || pixels_per_group <= 0 || Cp <= 0 || (Cp % 8))
+        return UCLSTM_E_BADARG;
+    const int64_t chunks = pixels * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (uint4*)a, scale,
+                       shift, chunks, make_fastdiv(Cp / 8), make_fastdiv((uint32_t)pixels_per_group), Cp);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, float* sums, int64_t pixels, int64_t pixels_per_group, int32_t Cp,
+                                        void* stream) {
+    if (!aligned16(z) || !aligned16(da) || !scale || !shift || !mean || !rstd || !sums || pixels <= 0 || pixels_per_group <= 0 ||
+        (pixels % pixels_per_group) || Cp <= 0 || (Cp % 8))
+        return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    const int groups = (int)(pixels / pixels_per_group);
+    int bpg = (int)((pixels_per_group + 255) / 256);          // >= 256 pixel rows per block
+    const int cap = (2048 + groups - 1) / groups;
+    if (bpg > cap) bpg = cap;
+    if (bpg < 1) bpg = 1;
+    const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
+    const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
+                       scale, shift, mean, rstd, sums, pixels_per_group, Cp, cg, bpg, ppb);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
+                                       const float* rstd, const float* sums, void* dz, int64_t pixels, int64_t pixels_per_group,
+                                       int32_t Cp, void* stream) {
+    if (!aligned16(z) || !aligned16(da) || !aligned16(dz) || !scale || !shift || !mean || !rstd || !sums || pixels <= 0 ||
+        pixels_per_group <= 0 || Cp <= 0 || (Cp % 8))
+        return UCLSTM_E_BADARG;
+    const int64_t chunks = pixels * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
+                       scale, shift, mean, rstd, sums, (uint4*)dz, chunks, make_fastdiv(Cp / 8),
+                       make_fastdiv((uint32_t)pixels_per_group), Cp, (float)(1.0 / (double)pixels_per_group));
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream) {
+    if (!aligned16(a) || !aligned16(p) || n_img <= 0 || H < 2 || W < 2 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t chunks = (int64_t)n_img * Ho * Wo * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (uint4*)p, chunks,
+                       make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp,
+                                       void* stream) {
+    if (!aligned16(a) || !aligned16(dp) || !aligned16(da) || n_img <= 0 || H < 2 || W < 2 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t chunks = (int64_t)n_img * Ho * Wo * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)dp,
+                       (uint4*)da, chunks, make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new, const void* dh_a,
+                                             const void* dh_b, float* dc_io, int32_t dc_is_zero, void* dgates, int64_t pixels,
+                                             int32_t Hd_p, void* stream) {
+    if (!aligned16(gates) || !aligned16(c_new) || !aligned16(dc_io) || !aligned16(dgates) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8))
+        return UCLSTM_E_BADARG;
+    if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return UCLSTM_E_BADARG;
+    const int64_t chunks = pixels * (Hd_p / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
+                       (const uint4*)dh_a, (const uint4*)dh_b, dc_io, dc_is_zero, (uint4*)dgates, chunks, make_fastdiv(Hd_p / 8));
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_nchw_to_nhwc(const float* x, void* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                                       int32_t inner, int64_t inner_stride, int64_t outer_stride, void* stream) {
+    if (!x || !aligned16(out) || n_img <= 0 || C <= 0 || Cp < C || (Cp % 8) || H <= 0 || W <= 0 || inner <= 0 || (n_img % inner))
+        return UCLSTM_E_BADARG;
+    const int64_t items = (int64_t)n_img * (Cp / 8) * H * W;
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Cp / 8,
+                       make_fastdiv(H * W), make_fastdiv(Cp / 8), make_fastdiv(inner), inner_stride, outer_stride);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_nchw_grad_to_nhwc(const float* g, void* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                                            void* stream) {
+    return uclstm_nchw_to_nhwc(g, out, n_img, C, Cp, H, W, n_img, 0, (int64_t)C * H * W, stream);
+}
+
+extern "C" int32_t uclstm_nhwc_to_nchw(const void* a, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                                       void* stream) {
+    if (!aligned16(a) || !out || n_img <= 0 || C <= 0 || Cp < C || (Cp % 8) || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
+    const int64_t items = (int64_t)n_img * (Cp / 8) * H * W;
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, out, items, C, Cp / 8,
+                       make_fastdiv(H * W), make_fastdiv(Cp / 8));
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_nchw_to_nhwc_f32(const float* x, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                                           void* stream) {
+    if (!x || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
+    const int64_t items = (int64_t)n_img * Cp * H * W;
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, out, items, C, Cp,
+                       make_fastdiv(H * W), make_fastdiv(Cp));
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_nhwc_to_nchw_f32(const float* a, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
+                                           void* stream) {
+    if (!a || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
+    const int64_t items = (int64_t)n_img * C * H * W;
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, a, out, items, C, Cp,
+                       make_fastdiv(H * W), make_fastdiv(C));
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_im2col3x3_first(const float* x, void* out, int32_t n_img, int32_t C, int32_t Kp, int32_t H, int32_t W,
+                                          int32_t inner, int64_t inner_stride, int64_t outer_stride, void* stream) {
+    if (!x || !aligned16(out) || n_img <= 0 || C <= 0 || Kp < 9 * C || (Kp % 8) || H <= 0 || W <= 0 || inner <= 0 || (n_img % inner))
+        return UCLSTM_E_BADARG;
+    const int64_t items = (int64_t)n_img * (Kp / 8) * H * W;
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(im2col_first_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Kp / 8, H, W,
+                       make_fastdiv(H * W), make_fastdiv(W), make_fastdiv(Kp / 8), make_fastdiv(inner), make_fastdiv(C), inner_stride,
+                       outer_stride);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_outconv_fwd(const void* a, const float* w, const float* b, float* y, int64_t n_img, int32_t HW, int32_t Cp,
+                                      int32_t C, int32_t Co, void* stream) {
+    if (!aligned16(a) || !w || !y || n_img <= 0 || HW <= 0 || Cp < C || (Cp % 8) || C <= 0 || Co <= 0) return UCLSTM_E_BADARG;
+    const int64_t pixels = n_img * HW;
+    if (pixels >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipLaunchKernelGGL(outconv_fwd_kernel, dim3(ew_grid(pixels)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, w, b, y, pixels,
+                       make_fastdiv(HW), Cp / 8, C, Co);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_outconv_bwd(const void* a, const float* w, const float* dy, void* da, float* dw, float* db, int64_t n_img,
+                                      int32_t HW, int32_t Cp, int32_t C, int32_t Co, void* stream) {
+    if (!aligned16(a) || !w || !dy || n_img <= 0 || HW <= 0 || Cp < C || (Cp % 8) || C <= 0 || Co <= 0 || Cp / 8 > NT)
+        return UCLSTM_E_BADARG;
+    const int64_t pixels = n_img * HW;
+    const int64_t chunks = pixels * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    if (da) {
+        if (!aligned16(da)) return UCLSTM_E_BADARG;
+        hipLaunchKernelGGL(outconv_bwd_da_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, w, dy, (uint4*)da, chunks,
+                           make_fastdiv(Cp / 8), make_fastdiv(HW), C, Co);
+        UCLSTM_CHECK_LAUNCH();
+    }
+    if (dw && db) {
+        const ColGeom cg = col_geom(Cp);
+        int nb = (int)((pixels + 1023) / 1024);
+        if (nb > 1024) nb = 1024;
+        const int64_t ppb = (pixels + nb - 1) / nb;
+        const size_t lds = (size_t)cg.rows * (cg.cpc * 8 + 1) * sizeof(float);
+        hipLaunchKernelGGL(outconv_bwd_dw_kernel, dim3(nb, Co), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, dy, dw, db, pixels,
+                           make_fastdiv(HW), cg, C, Co, ppb);
+        UCLSTM_CHECK_LAUNCH();
+    }
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int32_t Cp, void* stream) {
+    if (!aligned16(a) || !out || pixels <= 0 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    int nb = (int)((pixels + 511) / 512);
+    if (nb > 1024) nb = 1024;
+    const int64_t ppb = (pixels + nb - 1) / nb;
+    const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 8 * sizeof(float);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
+    UCLSTM_CHECK_LAUNCH();
+    return UCLSTM_OK;
+}

@@ -1,0 +1,95 @@
+"""Data-parallel training across the GPUs of one node: one process per GPU, sequences sharded over
+ranks, one gradient exchange per step.
+
+``FlatDDP`` all-reduces the flat gradient buffer of ``optim.FlatParams`` in contiguous buckets cut
+from the END of the buffer backwards: backward produces gradients in (nearly) reverse registration
+order -- decoder first, then the three ConvLSTM weights when their BPTT finishes, encoder last -- so
+each bucket is launched (async, on RCCL's own stream over xGMI) as soon as its last gradient has
+been accumulated and overlaps the rest of backward.  BatchNorm statistics stay local per rank
+(the reference has no SyncBN); parameters and buffers are broadcast from rank 0 once.
+
+Backend-agnostic: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import FlatParams
+
+
+class FlatDDP:
+    def __init__(self, module: torch.nn.Module, flat: FlatParams, bucket_mb: float = 64.0, process_group=None,
+                 broadcast: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("FlatDDP: torch.distributed is not initialised")
+        self.module, self.flat, self.pg = module, flat, process_group
+        self.world = dist.get_world_size(process_group)
+        if broadcast:
+            dist.broadcast(flat.flat_p, src=0, group=process_group)
+            for b in module.buffers():
+                dist.broadcast(b, src=0, group=process_group)
+        # buckets: contiguous [start, end) slices, last parameters first
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets: List[List[int]] = []          # parameter indices per bucket
+        self.ranges: List[tuple] = []
+        cur: List[int] = []
+        size = 0
+        for i in range(len(flat.params) - 1, -1, -1):
+            cur.append(i)
+            size += flat.params[i].numel()
+            if size >= cap or i == 0:
+                lo = flat.offsets[cur[-1]]
+                hi = flat.offsets[cur[0]] + flat.params[cur[0]].numel()
+                self.buckets.append(cur)
+                self.ranges.append((lo, hi))
+                cur, size = [], 0
+        self.bucket_of = {}
+        for bi, idxs in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[i] = bi
+        self._pending = [0] * len(self.buckets)
+        self._handles: List[Optional[object]] = [None] * len(self.buckets)
+        self._hooks = []
+        for i, p in enumerate(flat.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.reset()
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            bi = self.bucket_of[i]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi: int) -> None:
+        lo, hi = self.ranges[bi]
+        # gradients are produced on the compute stream; the collective's stream waits on it internally
+        self._handles[bi] = dist.all_reduce(self.flat.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def reset(self) -> None:
+        """Call before each backward (after zero_grad)."""
+        self._pending = [len(b) for b in self.buckets]
+        self._handles = [None] * len(self.buckets)
+
+    def finalize(self) -> None:
+        """Call after backward, before the optimiser step: launches buckets whose hooks did not all fire
+        (parameters unused in this step), waits for every collective and turns sums into means."""
+        for bi in range(len(self.buckets)):
+            if self._handles[bi] is None:
+                self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        if self.world > 1:
+            self.flat.flat_g.mul_(1.0 / self.world)
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)

@@ -1,0 +1,226 @@
+"""Training / evaluation step loop of the reference's main.py on the HIP path, plus data sources.
+
+``train_one_epoch`` / ``evaluate`` keep the reference signatures and return values
+(main.py:77-144, :150-205: ``(avg_loss, mae, rmse, mean_err)`` in de-normalised units) but keep
+the metric block on the device as running sums instead of per-pixel Python lists
+(main.py:114-133), and do not synchronise with the host inside the step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .loss import compute_loss
+from .optim import FusedAdamW
+
+
+# ---------------------------------------------------------------------------------------------
+# data
+# ---------------------------------------------------------------------------------------------
+class SyntheticSequences:
+    """Seeded synthetic batches in the post-normalisation ranges of the reference dataset
+    (X ~ U[0,1) as after ``x / norm_const``, train/unet.py:283; Y ~ U(-1,1) as
+    after the [-1,1] mapping, ``:299``; mask = cloud pixels).  ``kind='blobs'`` draws moving blobs with
+    integer velocities in [-5,5] and the bounce rule of digits/build_moving_mnist.py:38-47; X is the frame
+    duplicated into both "satellite" channels and Y the per-pixel vx map."""
+
+    def __init__(self, B: int, T: int, H: int, W: int, seed: int = 1, kind: str = "uniform", device="cuda", channels: int = 2):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        if kind == "uniform":
+            x = torch.rand((B, T, channels, H, W), generator=g)
+            y = torch.rand((B, T, 1, H, W), generator=g) * 2 - 1
+            mask = (torch.rand((B, T, 1, H, W), generator=g) > 0.3).float()
+        elif kind == "blobs":
+            x = torch.zeros((B, T, channels, H, W))
+            y = torch.zeros((B, T, 1, H, W))
+            yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            for b in range(B):
+                for _ in range(2):
+                    r = 4 + int(torch.randint(0, 4, (1,), generator=g))
+                    px = float(torch.randint(r, W - r, (1,), generator=g))
+                    py = float(torch.randint(r, H - r, (1,), generator=g))
+                    vx = int(torch.randint(-5, 6, (1,), generator=g))
+                    vy = int(torch.randint(-5, 6, (1,), generator=g))
+                    for t in range(T):
+                        blob = torch.exp(-((xx - px) ** 2 + (yy - py) ** 2) / (2.0 * (r / 2.0) ** 2))
+                        on = blob > 0.1
+                        x[b, t, :, on] = torch.maximum(x[b, t, :, on], blob[on])
+                        y[b, t, 0][on] = vx / 5.0
+                        px, py = px + vx, py + vy
+                        if px < r or px > W - 1 - r:
+                            vx = -vx
+                            px = min(max(px, r), W - 1 - r)
+                        if py < r or py > H - 1 - r:
+                            vy = -vy
+                            py = min(max(py, r), H - 1 - r)
+            mask = (x[:, :, 0:1] > 0.1).float()
+        else:
+            raise ValueError(kind)
+        self.x, self.y, self.mask = x.to(device), y.to(device), mask.to(device)
+
+    def __iter__(self):
+        yield self.x, self.y, self.mask
+
+    def __len__(self):
+        return 1
+
+
+class NPZSequenceDataset(torch.utils.data.Dataset):
+    """Host-side mirror of the reference dataset (train/unet.py:210-327): ``.npz`` with ``X [N,T,2,H,W]``,
+    ``Y [N,T,1,H,W]``; mask from RAW x > 1.1 (``:279``), x / max(x_max, 1) (``:220,:283``), Y clipped, asinh(y/scale)
+    and mapped to [-1,1] (``:287-299``).  ``denormalize`` accepts numpy or torch (any device) and stays on the
+    input's device for tensors."""
+
+    def __init__(self, npz_path, lower_percentile=0.00001, upper_percentile=99.99999, clip_outliers=True,
+                 min_y=-7.5987958908081055, max_y=8.784920692443848, y_transform="asinh", y_transform_scale=None,
+                 y_transform_percentile=99):
+        with np.load(npz_path, allow_pickle=False) as data:
+            self.X = data["X"].astype(np.float32)
+            self.Y = data["Y"].astype(np.float32)
+        self.N, self.T, _, self.H, self.W = self.X.shape
+        self.x_max = float(np.max(self.X))
+        self.norm_const = max(self.x_max, 1.0)
+        if y_transform not in ("asinh", "signed_log", None, "none"):
+            raise ValueError(y_transform)
+        self.y_transform = y_transform
+        if y_transform_scale is None:
+            self.y_scale = float(np.percentile(np.abs(self.Y), y_transform_percentile)) if y_transform_percentile is not None else 1.0
+        else:
+            self.y_scale = float(y_transform_scale)
+        explicit = (min_y is not None) and (max_y is not None)
+        if explicit:
+            self.min_vel, self.max_vel = float(min_y), float(max_y)
+            self.trans_min = float(self._fwd(np.float64(self.min_vel)))
+            self.trans_max = float(self._fwd(np.float64(self.max_vel)))
+        else:
+            self.min_vel = float(np.percentile(self.Y, lower_percentile))
+            self.max_vel = float(np.percentile(self.Y, upper_percentile))
+            yt = self._fwd(self.Y)
+            self.trans_min = float(np.percentile(yt, lower_percentile))
+            self.trans_max = float(np.percentile(yt, upper_percentile))
+        if self.trans_max == self.trans_min:
+            self.trans_max = self.trans_min + 1.0
+        self.clip_outliers = clip_outliers
+
+    def _fwd(self, arr):
+        if self.y_transform == "asinh":
+            return np.arcsinh(arr / self.y_scale)
+        if self.y_transform == "signed_log":
+            return np.sign(arr) * np.log1p(np.abs(arr) / self.y_scale)
+        return arr
+
+    def __len__(self):
+        return self.N
+
+    def __getitem__(self, idx):
+        x = torch.from_numpy(self.X[idx])
+        mask = (x[:, 0:1] > 1.1).float()
+        x = x / self.norm_const
+        y_raw = self.Y[idx]
+        if self.clip_outliers:
+            y_raw = np.clip(y_raw, self.min_vel, self.max_vel)
+        y_scaled = (2 * (self._fwd(y_raw) - self.trans_min) / (self.trans_max - self.trans_min) - 1.0).astype(np.float32)
+        return x, torch.from_numpy(y_scaled), mask
+
+    def denormalize(self, y_norm):
+        if isinstance(y_norm, torch.Tensor):
+            yt = (y_norm + 1.0) / 2.0 * (self.trans_max - self.trans_min) + self.trans_min
+            if self.y_transform == "asinh":
+                return torch.sinh(yt) * self.y_scale
+            if self.y_transform == "signed_log":
+                return torch.sign(yt) * torch.expm1(yt.abs()) * self.y_scale
+            return yt
+        yt = (y_norm + 1.0) / 2.0 * (self.trans_max - self.trans_min) + self.trans_min
+        if self.y_transform == "asinh":
+            return np.sinh(yt) * self.y_scale
+        if self.y_transform == "signed_log":
+            return np.sign(yt) * (np.expm1(np.abs(yt)) * self.y_scale)
+        return yt
+
+
+# ---------------------------------------------------------------------------------------------
+# step / epoch loops
+# ---------------------------------------------------------------------------------------------
+def _stack(output):
+    return torch.stack(output, dim=1) if isinstance(output, (list, tuple)) else output      # main.py:97-100
+
+
+def train_step(model, optimizer, x, y, mask=None, use_mask=True, ddp=None, clip_norm: Optional[float] = 1.0):
+    """zero_grad -> forward -> stack -> loss -> backward -> [gradient all-reduce] -> clip(1.0) -> optimiser step
+    (main.py:91-108).  Returns ``(loss, y_pred)`` as device tensors; nothing here waits for the GPU."""
+    optimizer.zero_grad(set_to_none=True)
+    if ddp is not None:
+        ddp.reset()
+    output, _ = model(x)
+    y_pred = _stack(output)
+    loss = compute_loss(y_pred, y, mask, use_mask)
+    loss.backward()
+    if ddp is not None:
+        ddp.finalize()
+    if isinstance(optimizer, FusedAdamW):
+        optimizer.max_grad_norm = clip_norm          # clip fused into the optimiser kernels (device-side coefficient)
+    elif clip_norm is not None:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)                         # main.py:106
+    optimizer.step()
+    return loss.detach(), y_pred.detach()
+
+
+class _Metrics:
+    """Running sums of |d|, d^2, d and the count on the device (replaces main.py:114-142)."""
+
+    def __init__(self, device):
+        self.s = torch.zeros(4, dtype=torch.float64, device=device)
+
+    @torch.no_grad()
+    def add(self, dataset_obj, y, y_pred, mask, use_mask):
+        d = (dataset_obj.denormalize(y_pred) - dataset_obj.denormalize(y)).double()
+        if use_mask:
+            m = (mask != 0).double()
+            self.s += torch.stack(((d.abs() * m).sum(), (d * d * m).sum(), (d * m).sum(), m.sum()))
+        else:
+            self.s += torch.stack((d.abs().sum(), (d * d).sum(), d.sum(),
+                                   torch.tensor(float(d.numel()), dtype=torch.float64, device=d.device)))
+
+    def result(self):
+        a, q, e, n = (float(v) for v in self.s.cpu())
+        if n <= 0:
+            return 0.0, 0.0, 0.0
+        return a / n, math.sqrt(q / n), e / n
+
+
+def train_one_epoch(model, loader, optimizer, device, dataset_obj, use_mask=True, ddp=None):
+    """Reference main.py:77-144; returns ``(avg_loss, avg_mae, avg_rmse, avg_me)``."""
+    model.train()
+    total = torch.zeros((), dtype=torch.float64, device=device)
+    n = 0
+    met = _Metrics(device)
+    for x, y, mask in loader:
+        x, y, mask = x.to(device, non_blocking=True), y.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+        loss, y_pred = train_step(model, optimizer, x, y, mask, use_mask, ddp)
+        total += loss.double() * x.size(0)
+        n += x.size(0)
+        met.add(dataset_obj, y, y_pred, mask, use_mask)
+    mae, rmse, me = met.result()
+    return float(total) / max(n, 1), mae, rmse, me
+
+
+@torch.no_grad()
+def evaluate(model, loader, device, dataset_obj, use_mask=True):
+    """Reference main.py:150-205."""
+    model.eval()
+    total = torch.zeros((), dtype=torch.float64, device=device)
+    n = 0
+    met = _Metrics(device)
+    for x, y, mask in loader:
+        x, y, mask = x.to(device, non_blocking=True), y.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+        output, _ = model(x)
+        y_pred = _stack(output)
+        loss = compute_loss(y_pred, y, mask, use_mask)
+        total += loss.double() * x.size(0)
+        n += x.size(0)
+        met.add(dataset_obj, y, y_pred, mask, use_mask)
+    mae, rmse, me = met.result()
+    return float(total) / max(n, 1), mae, rmse, me

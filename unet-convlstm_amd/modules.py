@@ -1,0 +1,316 @@
+"""nn.Module surface of the reference's train/unet.py, running on libuclstm.so.
+
+Same class names, constructor signatures, attribute names and ``state_dict`` keys as the
+reference, so checkpoints move both ways and the reference's training
+loop drives these modules unchanged.  Parameters live in stock ``nn.Conv2d`` /
+``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` containers (identical initialisation and RNG
+consumption as the reference), but those containers are never *called*: every forward goes
+through the HIP operators in ``ops.py``.
+
+Public ``forward`` methods take/return the reference's tensors (f32 NCHW); the ``*_nhwc``
+methods are the internal bf16 NHWC path that ``TemporalUNetDualView`` chains end to end with
+all T timesteps batched (BatchNorm statistics stay per timestep).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import UclstmError
+
+Tensor = torch.Tensor
+
+
+def _need_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvLSTM (reference train/unet.py:14-60)
+# ---------------------------------------------------------------------------------------------
+class ConvLSTMCell(nn.Module):
+    """Reference train/unet.py:14-36.  ``cell(x, state=None) -> (h, (h, c))`` on f32 NCHW."""
+
+    def __init__(self, input_dim, hidden_dim, kernel_size=3, bias=True):
+        super().__init__()
+        if kernel_size not in (1, 3):
+            raise UclstmError("ConvLSTMCell: the HIP path supports kernel_size 1 or 3 (every reference call site uses 3)")
+        padding = kernel_size // 2
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.conv = nn.Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size, padding=padding, bias=bias)
+
+    # internal: whole sequence, NHWC
+    def seq_nhwc(self, x_all: Tensor, h0: Optional[Tensor], c0: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+        need = _need_grad(x_all, h0, c0, self.conv.weight)
+        return ops.ConvLSTMSeq.apply(x_all, h0, c0, self.conv.weight, self.conv.bias, self.hidden_dim, self.input_dim, need)
+
+    def forward(self, x, state=None):
+        B, Cc, H, W = x.shape
+        xa = ops.ToNHWC.apply(x.contiguous().float()).unsqueeze(0)
+        h0 = c0 = None
+        if state is not None:
+            h, c = state
+            h0 = ops.ToNHWC.apply(h.contiguous().float())
+            c0 = ops.StateToNHWC.apply(c.contiguous().float())
+        h_all, c_T = self.seq_nhwc(xa, h0, c0)
+        h_next = ops.FromNHWC.apply(h_all[0], self.hidden_dim)
+        c_next = ops.StateFromNHWC.apply(c_T, self.hidden_dim)
+        return h_next, (h_next, c_next)
+
+
+class ConvLSTM(nn.Module):
+    """Reference train/unet.py:39-60: layer-major, time-minor stack; ``x_seq`` is any indexable of T tensors."""
+
+    def __init__(self, input_dim, hidden_dim, num_layers=1, kernel_size=3):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        for l in range(num_layers):
+            self.layers.append(ConvLSTMCell(input_dim if l == 0 else hidden_dim, hidden_dim, kernel_size))
+
+    def seq_nhwc(self, x_all: Tensor, state: Optional[Sequence]):
+        """x_all bf16 [T,B,H,W,Cp]; state: per layer None or (h bf16 NHWC, c f32 NHWC)."""
+        if state is None:
+            state = [None] * len(self.layers)
+        out = x_all
+        new_states = []
+        for li, layer in enumerate(self.layers):
+            h0, c0 = (None, None) if state[li] is None else state[li]
+            out, c_T = layer.seq_nhwc(out, h0, c0)
+            new_states.append((out[-1], c_T))
+        return out, new_states
+
+    def forward(self, x_seq, state=None):
+        T = len(x_seq)
+        xs = torch.stack([ops.ToNHWC.apply(x_seq[t].contiguous().float()) for t in range(T)], dim=0)
+        st = None
+        if state is not None:
+            st = []
+            for s in state:
+                if s is None or s[0] is None:
+                    st.append(None)
+                else:
+                    st.append((ops.ToNHWC.apply(s[0].contiguous().float()), ops.StateToNHWC.apply(s[1].contiguous().float())))
+        out, new_states = self.seq_nhwc(xs, st)
+        hd = self.layers[-1].hidden_dim
+        seq_out = [ops.FromNHWC.apply(out[t], hd) for t in range(T)]
+        states = [(ops.FromNHWC.apply(h, l.hidden_dim), ops.StateFromNHWC.apply(c, l.hidden_dim))
+                  for (h, c), l in zip(new_states, self.layers)]
+        return seq_out, states
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet blocks (reference train/unet.py:66-107)
+# ---------------------------------------------------------------------------------------------
+class DoubleConv(nn.Module):
+    """Reference train/unet.py:66-75: (conv3x3 + BN + ReLU) x 2, ``self.net`` indices 0,1,3,4 hold the parameters."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Conv2d(in_ch, out_ch, 3, padding=1), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True),
+            nn.Conv2d(out_ch, out_ch, 3, padding=1), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True)
+        )
+
+    def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False):
+        training = self.training or not bn.track_running_stats
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                 tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += groups      # the reference calls BN once per timestep
+        return a
+
+    def forward_nhwc(self, x0: Tensor, x1: Optional[Tensor] = None, c_valid=None, off=(0, 0), groups: int = 1,
+                     im2col: bool = False) -> Tensor:
+        conv0, bn0, conv1, bn1 = self.net[0], self.net[1], self.net[3], self.net[4]
+        if c_valid is None:
+            c_valid = (conv0.in_channels,)
+        a = self._stage(conv0, bn0, x0, x1, c_valid, off, groups, im2col)
+        return self._stage(conv1, bn1, a, None, (conv0.out_channels,), (0, 0), groups)
+
+    def first_layer_nhwc(self, x: Tensor, time_major: bool, groups: int) -> Tensor:
+        """f32 NCHW (or [B,T,C,H,W] with ``time_major``) input that needs no gradient -> pre-gathered first conv."""
+        cin = self.net[0].in_channels
+        if 9 * cin <= 64 and not x.requires_grad:
+            return self.forward_nhwc(ops.im2col_first(x.contiguous().float(), time_major), None, (cin,), (0, 0), groups, im2col=True)
+        if time_major:
+            B, T = x.shape[0], x.shape[1]
+            x = x.transpose(0, 1).reshape(B * T, *x.shape[2:])
+        return self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()), None, (cin,), (0, 0), groups)
+
+    def forward(self, x):
+        a = self.first_layer_nhwc(x, False, 1)
+        return ops.FromNHWC.apply(a, self.net[3].out_channels)
+
+
+class Down(nn.Module):
+    """Reference train/unet.py:78-84: ``Sequential(MaxPool2d(2), DoubleConv)`` -> keys ``net.1.net.N.*``."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.net = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_ch, out_ch))
+
+    def forward_nhwc(self, a: Tensor, groups: int = 1) -> Tensor:
+        return self.net[1].forward_nhwc(ops.MaxPool2.apply(a), groups=groups)
+
+    def forward(self, x):
+        a = self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()))
+        return ops.FromNHWC.apply(a, self.net[1].net[3].out_channels)
+
+
+class Up(nn.Module):
+    """Reference train/unet.py:87-98: ConvTranspose2d(k2,s2), centre-pad to the skip, cat([skip, up]), DoubleConv."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_ch, in_ch // 2, 2, stride=2)
+        self.conv = DoubleConv(in_ch, out_ch)
+
+    def forward_nhwc(self, x1: Tensor, x2: Tensor, skip_ch: int, groups: int = 1) -> Tensor:
+        u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
+        diffY = x2.shape[1] - u.shape[1]
+        diffX = x2.shape[2] - u.shape[2]
+        if diffY < 0 or diffX < 0:
+            raise UclstmError("Up: the upsampled map is larger than the skip map (negative F.pad is not supported)")
+        # cat order is skip first (train/unet.py:98); the pad is folded into the source view offsets
+        return self.conv.forward_nhwc(x2, u, (skip_ch, self.up.out_channels), (diffY // 2, diffX // 2), groups)
+
+    def forward(self, x1, x2):
+        a = self.forward_nhwc(ops.ToNHWC.apply(x1.contiguous().float()), ops.ToNHWC.apply(x2.contiguous().float()), x2.shape[1])
+        return ops.FromNHWC.apply(a, self.conv.net[3].out_channels)
+
+
+class OutConv(nn.Module):
+    """Reference train/unet.py:101-107."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = nn.Conv2d(in_ch, out_ch, 1)
+
+    def forward_nhwc(self, a: Tensor) -> Tensor:
+        w = self.conv.weight
+        return ops.OutConv1x1.apply(a, w.view(w.shape[0], w.shape[1]), self.conv.bias)
+
+    def forward(self, x):
+        return self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()))
+
+
+class SpatialAttention(nn.Module):
+    """Reference train/unet.py:113-125.  Off in every reference script (main.py:226); kept on stock
+    PyTorch-ROCm ops (SURVEY.md section 8a row 8'), outside the hand-written hot path."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        padding = kernel_size // 2
+        self.conv = nn.Conv2d(2, 1, kernel_size, padding=padding, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        avg_out = x.mean(dim=1, keepdim=True)
+        max_out, _ = x.max(dim=1, keepdim=True)
+        attention = self.sigmoid(self.conv(torch.cat([avg_out, max_out], dim=1)))
+        return x * attention
+
+    def forward_nhwc(self, a: Tensor, channels: int) -> Tensor:
+        x = ops.FromNHWC.apply(a, channels)
+        return ops.ToNHWC.apply(self.forward(x).contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+# TemporalUNetDualView (reference train/unet.py:131-204)
+# ---------------------------------------------------------------------------------------------
+class TemporalUNetDualView(nn.Module):
+    """Reference train/unet.py:131-204.
+
+    ``model(x_seq[B,T,2*in_channels_per_sat,H,W], state=None) -> (list of T [B,out,H,W] f32, new_state)``
+    where ``new_state`` is ``[(h, c)]`` per layer of ``self.temporal`` only (skip-LSTM states are
+    dropped exactly like the reference, ``:190-191``).
+    """
+
+    def __init__(self, in_channels_per_sat=1, out_channels=1, base_ch=32, lstm_layers=1, use_skip_lstm=False, use_attention=False):
+        super().__init__()
+        in_ch_total = in_channels_per_sat * 2
+        self.inc = DoubleConv(in_ch_total, base_ch)
+        self.down1 = Down(base_ch, base_ch * 2)
+        self.down2 = Down(base_ch * 2, base_ch * 4)
+        self.down3 = Down(base_ch * 4, base_ch * 8)
+        self.bottleneck = Down(base_ch * 8, base_ch * 16)
+
+        self.use_attention = use_attention
+        if self.use_attention:
+            self.attention = SpatialAttention()
+
+        self.temporal = ConvLSTM(base_ch * 16, base_ch * 16, num_layers=lstm_layers)
+
+        self.use_skip_lstm = use_skip_lstm
+        if use_skip_lstm:
+            self.lstm_skip3 = ConvLSTM(base_ch * 8, base_ch * 8)
+            self.lstm_skip2 = ConvLSTM(base_ch * 4, base_ch * 4)
+
+        self.up3 = Up(base_ch * 16, base_ch * 8)
+        self.up2 = Up(base_ch * 8, base_ch * 4)
+        self.up1 = Up(base_ch * 4, base_ch * 2)
+        self.up0 = Up(base_ch * 2, base_ch)
+        self.outc = OutConv(base_ch, out_channels)
+        self.base_ch = base_ch
+        self.out_channels = out_channels
+
+    # -- internal NHWC encoder over n images in `groups` BatchNorm groups
+    def _encode_nhwc(self, x: Tensor, time_major: bool, groups: int):
+        x0 = self.inc.first_layer_nhwc(x, time_major, groups)
+        x1 = self.down1.forward_nhwc(x0, groups)
+        x2 = self.down2.forward_nhwc(x1, groups)
+        x3 = self.down3.forward_nhwc(x2, groups)
+        xb = self.bottleneck.forward_nhwc(x3, groups)
+        if self.use_attention:
+            xb = self.attention.forward_nhwc(xb, self.base_ch * 16)
+        return xb, (x3, x2, x1, x0)
+
+    def encode_once(self, x_t):
+        """Reference train/unet.py:161-172 on f32 NCHW (public helper, one timestep)."""
+        xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
+        c = self.base_ch
+        f = ops.FromNHWC.apply
+        return f(xb, c * 16), (f(x3, c * 8), f(x2, c * 4), f(x1, c * 2), f(x0, c))
+
+    def forward(self, x_seq, state=None):
+        B, T, Cc, H, W = x_seq.shape
+        c = self.base_ch
+        # encoder: all T timesteps as one batch of T*B images (time-major), BN statistics per timestep
+        xb, (x3, x2, x1, x0) = self._encode_nhwc(x_seq, True, T)
+
+        def seq(t: Tensor) -> Tensor:          # [T*B,h,w,C] -> [T,B,h,w,C]
+            return t.view(T, B, *t.shape[1:])
+
+        st = None
+        if state is not None:
+            st = []
+            for s in state:
+                if s is None or s[0] is None:
+                    st.append(None)
+                else:
+                    st.append((ops.ToNHWC.apply(s[0].contiguous().float()), ops.StateToNHWC.apply(s[1].contiguous().float())))
+        b_all, new_st = self.temporal.seq_nhwc(seq(xb), st)
+        if self.use_skip_lstm:
+            x3_l, _ = self.lstm_skip3.seq_nhwc(seq(x3), None)
+            x2_l, _ = self.lstm_skip2.seq_nhwc(seq(x2), None)
+            x3 = x3_l.reshape(T * B, *x3_l.shape[2:])
+            x2 = x2_l.reshape(T * B, *x2_l.shape[2:])
+        b_flat = b_all.reshape(T * B, *b_all.shape[2:])
+
+        d3 = self.up3.forward_nhwc(b_flat, x3, c * 8, T)
+        d2 = self.up2.forward_nhwc(d3, x2, c * 4, T)
+        d1 = self.up1.forward_nhwc(d2, x1, c * 2, T)
+        d0 = self.up0.forward_nhwc(d1, x0, c, T)
+        y = self.outc.forward_nhwc(d0).view(T, B, self.out_channels, H, W)
+        out_seq = [y[t] for t in range(T)]
+
+        new_state = [(ops.FromNHWC.apply(h, c * 16), ops.StateFromNHWC.apply(cc, c * 16)) for (h, cc) in new_st]
+        return out_seq, new_state
+
+
+UNet = TemporalUNetDualView   # BASELINE.json calls the model "UNet"; the reference class is TemporalUNetDualView

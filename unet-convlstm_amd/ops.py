@@ -1,0 +1,719 @@
+"""Host-side operator layer over the C ABI (include/uclstm.h).
+
+Internal activation format: ``torch.bfloat16`` tensor ``[N, H, W, Cp]`` (NHWC, ``Cp`` = channels
+padded to a multiple of 8, padding channels are exactly zero); cell state is ``float32`` in the
+same layout.  PyTorch is used here only for device memory, the current HIP stream and autograd
+bookkeeping -- every arithmetic kernel is in libuclstm.so.  Nothing in this file runs on CPU
+tensors: ``_dev`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def cpad(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def kseg(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype=None, what: str = "tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.UclstmError(f"{what}: a HIP device tensor is required (this package has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise L.UclstmError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.UclstmError(f"{what}: must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# descriptors
+# ---------------------------------------------------------------------------------------------
+class SrcView:
+    """One input of a convolution: NHWC bf16 tensor placed at (offY, offX) in the output frame."""
+
+    def __init__(self, t: torch.Tensor, offY: int = 0, offX: int = 0):
+        _dev(t, BF16, "conv source")
+        assert t.dim() == 4 and t.shape[3] % 8 == 0
+        self.t, self.offY, self.offX = t, offY, offX
+
+    def fill(self, s: L.Src):
+        s.ptr = self.t.data_ptr()
+        s.C = self.t.shape[3]
+        s.Hs, s.Ws = self.t.shape[1], self.t.shape[2]
+        s.offY, s.offX = self.offY, self.offX
+
+
+def _fill_seg(sg: L.Seg, t: torch.Tensor, n_begin: int, n_end: int, c_off: int = 0, scale: int = 1, oy: int = 0, ox: int = 0):
+    sg.ptr = t.data_ptr()
+    sg.n_begin, sg.n_end = n_begin, n_end
+    sg.C, sg.c_off = t.shape[3], c_off
+    sg.Hd, sg.Wd = t.shape[1], t.shape[2]
+    sg.scale, sg.oy, sg.ox = scale, oy, ox
+
+
+def conv_pack_desc(Co: int, Ci_total: int, c_valid: Sequence[int], c_pad: Sequence[int]) -> L.PackDesc:
+    """Forward panel of a 3x3 conv whose input is the channel concat of the sources (train/unet.py:70,:98)."""
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = cpad(Co), 9, len(c_valid)
+    for i in range(2):
+        d.kseg[i] = kseg(c_pad[i]) if i < len(c_valid) else 0
+        d.cvalid[i] = c_valid[i] if i < len(c_valid) else 0
+    d.choff[0], d.choff[1] = 0, c_valid[0]
+    d.Ktot = 9 * (d.kseg[0] + d.kseg[1])
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_IDENTITY, Co, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = Ci_total * 9, 9, 1, 0
+    return d
+
+
+def conv_dgrad_pack_desc(Co: int, Ci_total: int, c_valid_s: int) -> L.PackDesc:
+    """Input-gradient panel for ONE source: rows = its input channels, K = (flipped tap, out channel)."""
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = cpad(c_valid_s), 9, 1
+    d.kseg[0], d.kseg[1] = kseg(cpad(Co)), 0
+    d.cvalid[0], d.cvalid[1] = Co, 0
+    d.choff[0], d.choff[1] = 0, 0
+    d.Ktot = 9 * d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_IDENTITY, c_valid_s, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 1
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = 9, Ci_total * 9, 1, 0
+    return d
+
+
+def im2col_pack_desc(Co: int, Ci: int, Kp: int) -> L.PackDesc:
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = cpad(Co), 1, 1
+    d.kseg[0], d.kseg[1] = kseg(Kp), 0
+    d.cvalid[0], d.cvalid[1] = 9 * Ci, 0
+    d.choff[0] = d.choff[1] = 0
+    d.Ktot = d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_IDENTITY, Co, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IM2COL, 9, Ci, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = Ci * 9, 9, 1, 0
+    return d
+
+
+def lstm_pack_desc(Hd: int, Cx: int, ksize: int = 3) -> L.PackDesc:
+    """Gate-interleaved forward panel of the ConvLSTM gate conv [4Hd, Cx+Hd, k, k] (train/unet.py:19)."""
+    taps = ksize * ksize
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = 64 * ((Hd + 15) // 16), taps, 2
+    d.kseg[0], d.kseg[1] = kseg(cpad(Cx)), kseg(cpad(Hd))
+    d.cvalid[0], d.cvalid[1] = Cx, Hd
+    d.choff[0], d.choff[1] = 0, Cx
+    d.Ktot = taps * (d.kseg[0] + d.kseg[1])
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_LSTM, Hd, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = (Cx + Hd) * taps, taps, 1, 0
+    return d
+
+
+def lstm_dgrad_pack_desc(Hd: int, Cx: int, c_valid_s: int, ksize: int = 3) -> L.PackDesc:
+    """Input-gradient panel of the gate conv for one source (x or h); K = (flipped tap, gate*Hd_p + hc)."""
+    taps = ksize * ksize
+    Hdp = cpad(Hd)
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = cpad(c_valid_s), taps, 1
+    d.kseg[0], d.kseg[1] = kseg(4 * Hdp), 0
+    d.cvalid[0], d.cvalid[1] = 4 * Hd, 0
+    d.choff[0] = d.choff[1] = 0
+    d.Ktot = taps * d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_IDENTITY, c_valid_s, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_GATES, Hdp, Hd, 1
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = taps, (Cx + Hd) * taps, 1, 0
+    return d
+
+
+def lstm_wgrad_unpack_desc(Hd: int, Cx: int, ksize: int = 3) -> L.PackDesc:
+    """Panel-gradient layout of the gate conv: rows = gate*Hd_p + hc (the dgates channel order)."""
+    taps = ksize * ksize
+    Hdp = cpad(Hd)
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = 4 * Hdp, taps, 2
+    d.kseg[0], d.kseg[1] = kseg(cpad(Cx)), kseg(Hdp)
+    d.cvalid[0], d.cvalid[1] = Cx, Hd
+    d.choff[0], d.choff[1] = 0, Cx
+    d.Ktot = taps * (d.kseg[0] + d.kseg[1])
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_TAPMAJOR, Hd, Hdp
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap = (Cx + Hd) * taps, taps, 1
+    d.stride_ntap = Hd * (Cx + Hd) * taps
+    return d
+
+
+def convt_pack_desc(Ci: int, Co: int) -> L.PackDesc:
+    """Forward panel of ConvTranspose2d(Ci, Co, 2, stride 2): rows (tap, co), K = ci (weight [Ci,Co,2,2], train/unet.py:90)."""
+    Cop = cpad(Co)
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = 4 * Cop, 1, 1
+    d.kseg[0], d.kseg[1] = kseg(cpad(Ci)), 0
+    d.cvalid[0], d.cvalid[1] = Ci, 0
+    d.choff[0] = d.choff[1] = 0
+    d.Ktot = d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_TAPMAJOR, Co, Cop
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = 4, Co * 4, 0, 1
+    return d
+
+
+def convt_dgrad_pack_desc(Ci: int, Co: int) -> L.PackDesc:
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = cpad(Ci), 4, 1
+    d.kseg[0], d.kseg[1] = kseg(cpad(Co)), 0
+    d.cvalid[0], d.cvalid[1] = Co, 0
+    d.choff[0] = d.choff[1] = 0
+    d.Ktot = 4 * d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_IDENTITY, Ci, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = Co * 4, 4, 1, 0
+    return d
+
+
+def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0) -> torch.Tensor:
+    _dev(w, F32, "weight")
+    wp = torch.empty((desc.N, desc.Ktot), dtype=BF16, device=w.device)
+    L.check(L.lib.uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * elem_offset), _p(wp), _stream()), "pack_weights")
+    return wp
+
+
+def pack_bias(desc: L.PackDesc, b: torch.Tensor) -> torch.Tensor:
+    _dev(b, F32, "bias")
+    bp = torch.empty((desc.N,), dtype=F32, device=b.device)
+    L.check(L.lib.uclstm_pack_bias(C.byref(desc), _p(b), _p(bp), _stream()), "pack_bias")
+    return bp
+
+
+def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    grad = torch.empty_like(like, dtype=F32, memory_format=torch.contiguous_format)
+    L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), _p(grad), 0, _stream()), "unpack_wgrad")
+    return grad
+
+
+# ---------------------------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------------------------
+def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, segs, *, ktap: int, scale: int = 1,
+                pad: int = 0, groups: int = 1, bias=None, col_scale=None, col_shift=None, relu: bool = False, stats=None) -> None:
+    """segs: list of (tensor, n_begin, n_end, c_off, scale, oy, ox)."""
+    d = L.IgemmDesc()
+    d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], groups
+    d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
+    for i, s in enumerate(srcs):
+        s.fill(d.src[i])
+    d.wp, d.N, d.Ktot = wp.data_ptr(), wp.shape[0], wp.shape[1]
+    d.bias = None if bias is None else bias.data_ptr()
+    d.col_scale = None if col_scale is None else col_scale.data_ptr()
+    d.col_shift = None if col_shift is None else col_shift.data_ptr()
+    d.relu, d.epi = int(relu), L.EPI_STORE
+    d.nseg = len(segs)
+    for i, sg in enumerate(segs):
+        _fill_seg(d.seg[i], *sg)
+    d.stats = None if stats is None else stats.data_ptr()
+    L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)")
+
+
+def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
+               c_out: torch.Tensor, h_out: torch.Tensor, gates_out: Optional[torch.Tensor], ksize: int = 3) -> None:
+    d = L.IgemmDesc()
+    B, H, W, _ = x.shape
+    d.n_img, d.H, d.W, d.groups = B, H, W, 1
+    d.ktap, d.scale, d.pad, d.nsrc = ksize, 1, ksize // 2, 2
+    SrcView(x).fill(d.src[0])
+    SrcView(h_prev).fill(d.src[1])
+    d.wp, d.N, d.Ktot = wp.data_ptr(), wp.shape[0], wp.shape[1]
+    d.bias = None if bias is None else bias.data_ptr()
+    d.relu, d.epi, d.nseg = 0, L.EPI_LSTM, 0
+    d.Hd_p = h_prev.shape[3]
+    d.c_prev = None if c_prev is None else c_prev.data_ptr()
+    d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
+    d.gates_out = None if gates_out is None else gates_out.data_ptr()
+    L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)")
+
+
+def wgrad_splits(n_tiles: int, pixels: int) -> int:
+    """Pixel-range splits so that the grid reaches ~1024 blocks without dropping under 256 pixels per split."""
+    target = max(1, 1024 // max(n_tiles, 1))
+    return max(1, min(target, (pixels + 255) // 256))
+
+
+def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
+                pad: int = 0) -> torch.Tensor:
+    dev = srcs[0].t.device
+    dwp = torch.zeros((N, Ktot), dtype=F32, device=dev)
+    d = L.WgradDesc()
+    d.n_img, d.H, d.W = n_img, out_hw[0], out_hw[1]
+    d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
+    for i, s in enumerate(srcs):
+        s.fill(d.src[i])
+    d.N, d.Ktot = N, Ktot
+    d.nseg = len(dy_segs)
+    for i, sg in enumerate(dy_segs):
+        _fill_seg(d.seg[i], *sg)
+    d.dwp = dwp.data_ptr()
+    taps = ktap * ktap
+    n_tiles = ((N + 127) // 128) * taps * sum((s.t.shape[3] + 127) // 128 for s in srcs)
+    d.splits = wgrad_splits(n_tiles, n_img * out_hw[0] * out_hw[1])
+    d.accumulate = 1
+    L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad")
+    return dwp
+
+
+def colsum(a: torch.Tensor) -> torch.Tensor:
+    _dev(a, BF16, "colsum input")
+    Cp = a.shape[-1]
+    out = torch.zeros((Cp,), dtype=F32, device=a.device)
+    L.check(L.lib.uclstm_colsum(_p(a), _p(out), a.numel() // Cp, Cp, _stream()), "colsum")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# layout conversion at the module boundary
+# ---------------------------------------------------------------------------------------------
+class ToNHWC(torch.autograd.Function):
+    """f32 NCHW [N,C,H,W] -> bf16 NHWC [N,H,W,Cp]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x, F32, "input")
+        N, Cc, H, W = x.shape
+        out = torch.empty((N, H, W, cpad(Cc)), dtype=BF16, device=x.device)
+        L.check(L.lib.uclstm_nchw_to_nhwc(_p(x), _p(out), N, Cc, cpad(Cc), H, W, N, 0, Cc * H * W, _stream()), "nchw_to_nhwc")
+        ctx.C = Cc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, H, W, Cp = g.shape
+        out = torch.empty((N, ctx.C, H, W), dtype=F32, device=g.device)
+        L.check(L.lib.uclstm_nhwc_to_nchw(_p(g), _p(out), N, ctx.C, Cp, H, W, _stream()), "nhwc_to_nchw")
+        return out
+
+
+class FromNHWC(torch.autograd.Function):
+    """bf16 NHWC [N,H,W,Cp] -> f32 NCHW [N,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, a, Cc):
+        _dev(a, BF16, "activation")
+        N, H, W, Cp = a.shape
+        out = torch.empty((N, Cc, H, W), dtype=F32, device=a.device)
+        L.check(L.lib.uclstm_nhwc_to_nchw(_p(a), _p(out), N, Cc, Cp, H, W, _stream()), "nhwc_to_nchw")
+        ctx.Cp = Cp
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, Cc, H, W = g.shape
+        out = torch.empty((N, H, W, ctx.Cp), dtype=BF16, device=g.device)
+        L.check(L.lib.uclstm_nchw_grad_to_nhwc(_p(g), _p(out), N, Cc, ctx.Cp, H, W, _stream()), "nchw_grad_to_nhwc")
+        return out, None
+
+
+class StateToNHWC(torch.autograd.Function):
+    """f32 NCHW cell state -> f32 NHWC [N,H,W,Cp]."""
+
+    @staticmethod
+    def forward(ctx, c):
+        _dev(c, F32, "cell state")
+        N, Cc, H, W = c.shape
+        out = torch.empty((N, H, W, cpad(Cc)), dtype=F32, device=c.device)
+        L.check(L.lib.uclstm_nchw_to_nhwc_f32(_p(c), _p(out), N, Cc, cpad(Cc), H, W, _stream()), "nchw_to_nhwc_f32")
+        ctx.C = Cc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, H, W, Cp = g.shape
+        out = torch.empty((N, ctx.C, H, W), dtype=F32, device=g.device)
+        L.check(L.lib.uclstm_nhwc_to_nchw_f32(_p(g), _p(out), N, ctx.C, Cp, H, W, _stream()), "nhwc_to_nchw_f32")
+        return out
+
+
+class StateFromNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, Cc):
+        _dev(c, F32, "cell state")
+        N, H, W, Cp = c.shape
+        out = torch.empty((N, Cc, H, W), dtype=F32, device=c.device)
+        L.check(L.lib.uclstm_nhwc_to_nchw_f32(_p(c), _p(out), N, Cc, Cp, H, W, _stream()), "nhwc_to_nchw_f32")
+        ctx.Cp = Cp
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, Cc, H, W = g.shape
+        out = torch.empty((N, H, W, ctx.Cp), dtype=F32, device=g.device)
+        L.check(L.lib.uclstm_nchw_to_nhwc_f32(_p(g), _p(out), N, Cc, ctx.Cp, H, W, _stream()), "nchw_to_nhwc_f32")
+        return out, None
+
+
+def im2col_first(x: torch.Tensor, time_major: bool) -> torch.Tensor:
+    """First-layer gather of a f32 input that needs no gradient.
+
+    ``x`` is ``[N,C,H,W]`` or, with ``time_major``, ``[B,T,C,H,W]`` read as image ``t*B+b``
+    (train/unet.py:180 feeds ``x_seq[:, t]``).  Returns bf16 ``[N,H,W,Kp]`` with K = (tap, c).
+    """
+    _dev(x, F32, "input")
+    if time_major:
+        B, T, Cc, H, W = x.shape
+        n_img, inner, inner_stride, outer_stride = B * T, B, Cc * H * W, T * Cc * H * W
+    else:
+        n_img, Cc, H, W = x.shape
+        inner, inner_stride, outer_stride = n_img, 0, Cc * H * W
+    Kp = cpad(9 * Cc)
+    out = torch.empty((n_img, H, W, Kp), dtype=BF16, device=x.device)
+    L.check(L.lib.uclstm_im2col3x3_first(_p(x), _p(out), n_img, Cc, Kp, H, W, inner, inner_stride, outer_stride, _stream()),
+            "im2col3x3_first")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# conv3x3 (+ optional second source) + BatchNorm + ReLU   (train/unet.py:70-71, :98)
+# ---------------------------------------------------------------------------------------------
+class ConvBNReLU(torch.autograd.Function):
+    """One (conv3x3 pad 1 + bias -> BatchNorm2d -> ReLU) stage on NHWC bf16.
+
+    ``x1`` (optional) is channel-concatenated after ``x0`` and may be smaller, centred by
+    ``(offY, offX)`` (the F.pad of train/unet.py:95-97).  ``groups`` = number of BatchNorm
+    statistic groups along the image axis (timesteps).  ``im2col=True`` means ``x0`` is the
+    pre-gathered first-layer tensor (K = 9*Cin) and the conv runs as a plain GEMM.
+    """
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, gamma, beta, running_mean, running_var, c_valid, off, groups, training, momentum, eps,
+                im2col):
+        _dev(x0, BF16, "x0")
+        Co, Ci_total = weight.shape[0], weight.shape[1]
+        Cop = cpad(Co)
+        n_img, H, W, _ = x0.shape
+        dev = x0.device
+        if im2col:
+            pd = im2col_pack_desc(Co, Ci_total, x0.shape[3])
+            srcs = [SrcView(x0)]
+            ktap, pad = 1, 0
+        else:
+            c_pad = [x0.shape[3]] + ([x1.shape[3]] if x1 is not None else [])
+            pd = conv_pack_desc(Co, Ci_total, list(c_valid), c_pad)
+            srcs = [SrcView(x0)] + ([SrcView(x1, off[0], off[1])] if x1 is not None else [])
+            ktap, pad = 3, 1
+        wp = pack_weights(pd, weight)
+        bp = pack_bias(pd, bias) if bias is not None else None
+        out = torch.empty((n_img, H, W, Cop), dtype=BF16, device=dev)
+        ppg = (n_img // groups) * H * W
+        if training:
+            tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups)
+            stats = torch.empty((groups, tpg, Cop, 2), dtype=F32, device=dev)
+            z = out
+            igemm_store(srcs, wp, (H, W), n_img, [(z, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=groups, bias=bp, stats=stats)
+            par = torch.empty((4, groups, Cop), dtype=F32, device=dev)     # scale, shift, mean, rstd
+            L.check(L.lib.uclstm_bn_finalize(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), _p(running_mean),
+                                             _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
+                                             _stream()), "bn_finalize")
+            a = torch.empty_like(z)
+            L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
+                    "bn_apply_relu")
+            ctx.save_for_backward(x0, x1, weight, z, par, gamma)
+        else:
+            par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
+            L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                             momentum, eps, _p(par[0]), _p(par[1]), None, None, _stream()), "bn_finalize(eval)")
+            a = out
+            igemm_store(srcs, wp, (H, W), n_img, [(a, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp,
+                        col_scale=par[0], col_shift=par[1], relu=True)
+            ctx.save_for_backward(x0, x1, weight, None, None, gamma)
+        ctx.cfg = (tuple(c_valid), tuple(off), groups, training, im2col, Co, Ci_total, bias is not None)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x0, x1, weight, z, par, gamma = ctx.saved_tensors
+        c_valid, off, groups, training, im2col, Co, Ci_total, has_bias = ctx.cfg
+        if not training:
+            raise L.UclstmError("backward through eval-mode BatchNorm is not implemented (reference trains in train mode)")
+        da = da.contiguous()
+        n_img, H, W, Cop = z.shape
+        dev = z.device
+        pixels, ppg = n_img * H * W, (n_img // groups) * H * W
+        sums = torch.zeros((groups, Cop, 2), dtype=F32, device=dev)
+        L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), pixels, ppg, Cop,
+                                           _stream()), "bn_bwd_reduce")
+        dz = torch.empty_like(z)
+        L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), _p(dz), pixels, ppg,
+                                          Cop, _stream()), "bn_bwd_apply")
+        tot = sums.sum(dim=0)
+        dbeta = tot[:Co, 0].contiguous()
+        dgamma = tot[:Co, 1].contiguous()
+        # conv bias feeds BatchNorm, which removes any per-channel constant: its gradient is analytically 0
+        dbias = torch.zeros((Co,), dtype=F32, device=dev) if has_bias else None
+
+        dy_seg = [(dz, 0, Cop, 0, 1, 0, 0)]
+        if im2col:
+            pd = im2col_pack_desc(Co, Ci_total, x0.shape[3])
+            dwp = igemm_wgrad([SrcView(x0)], dy_seg, pd.N, pd.Ktot, (H, W), n_img, ktap=1, pad=0)
+        else:
+            c_pad = [x0.shape[3]] + ([x1.shape[3]] if x1 is not None else [])
+            pd = conv_pack_desc(Co, Ci_total, list(c_valid), c_pad)
+            srcs = [SrcView(x0)] + ([SrcView(x1, off[0], off[1])] if x1 is not None else [])
+            dwp = igemm_wgrad(srcs, dy_seg, pd.N, pd.Ktot, (H, W), n_img, ktap=3, pad=1)
+        dweight = unpack_wgrad(pd, dwp, weight)
+
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] and not im2col:
+            dd = conv_dgrad_pack_desc(Co, Ci_total, c_valid[0])
+            wd = pack_weights(dd, weight, 0)
+            dx0 = torch.empty_like(x0)
+            igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx0, 0, dd.N, 0, 1, 0, 0)], ktap=3, pad=1)
+        if x1 is not None and ctx.needs_input_grad[1]:
+            dd = conv_dgrad_pack_desc(Co, Ci_total, c_valid[1])
+            wd = pack_weights(dd, weight, c_valid[0] * 9)
+            dx1 = torch.empty_like(x1)
+            igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx1, 0, dd.N, 0, 1, -off[0], -off[1])], ktap=3, pad=1)
+        return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# MaxPool2d(2)  (train/unet.py:81)
+# ---------------------------------------------------------------------------------------------
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        _dev(a, BF16, "activation")
+        N, H, W, Cp = a.shape
+        p = torch.empty((N, H // 2, W // 2, Cp), dtype=BF16, device=a.device)
+        L.check(L.lib.uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(a)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (a,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        N, H, W, Cp = a.shape
+        da = torch.zeros_like(a) if (H % 2 or W % 2) else torch.empty_like(a)
+        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), _p(da), N, H, W, Cp, _stream()), "maxpool2_bwd")
+        return da
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvTranspose2d(k=2, s=2)  (train/unet.py:90, :94)
+# ---------------------------------------------------------------------------------------------
+class ConvT2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, BF16, "activation")
+        Ci, Co = weight.shape[0], weight.shape[1]
+        Cop = cpad(Co)
+        N, h, w, _ = x.shape
+        pd = convt_pack_desc(Ci, Co)
+        wp = pack_weights(pd, weight)
+        bp = pack_bias(pd, bias) if bias is not None else None
+        u = torch.empty((N, 2 * h, 2 * w, Cop), dtype=BF16, device=x.device)
+        segs = [(u, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
+        igemm_store([SrcView(x)], wp, (h, w), N, segs, ktap=1, pad=0, bias=bp)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        x, weight = ctx.saved_tensors
+        du = du.contiguous()
+        Ci, Co = weight.shape[0], weight.shape[1]
+        Cop = cpad(Co)
+        N, h, w, _ = x.shape
+        pd = convt_pack_desc(Ci, Co)
+        segs = [(du, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
+        dwp = igemm_wgrad([SrcView(x)], segs, pd.N, pd.Ktot, (h, w), N, ktap=1, pad=0)
+        dweight = unpack_wgrad(pd, dwp, weight)
+        dbias = colsum(du)[:Co].contiguous() if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dd = convt_dgrad_pack_desc(Ci, Co)
+            wd = pack_weights(dd, weight)
+            dx = torch.empty_like(x)
+            igemm_store([SrcView(du)], wd, (h, w), N, [(dx, 0, dd.N, 0, 1, 0, 0)], ktap=2, scale=2, pad=0)
+        return dx, dweight, dbias
+
+
+# ---------------------------------------------------------------------------------------------
+# OutConv 1x1  (train/unet.py:101-107)
+# ---------------------------------------------------------------------------------------------
+class OutConv1x1(torch.autograd.Function):
+    """bf16 NHWC in, f32 NCHW out (the model's public output dtype/layout)."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias):
+        _dev(a, BF16, "activation")
+        N, H, W, Cp = a.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        y = torch.empty((N, Co, H, W), dtype=F32, device=a.device)
+        L.check(L.lib.uclstm_outconv_fwd(_p(a), _p(weight), _p(bias), _p(y), N, H * W, Cp, Ci, Co, _stream()), "outconv_fwd")
+        ctx.save_for_backward(a, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        N, H, W, Cp = a.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros((Co, Ci), dtype=F32, device=a.device)
+        db = torch.zeros((Co,), dtype=F32, device=a.device)
+        L.check(L.lib.uclstm_outconv_bwd(_p(a), _p(weight), _p(dy), _p(da), _p(dw), _p(db), N, H * W, Cp, Ci, Co, _stream()),
+                "outconv_bwd")
+        return da, dw.view_as(weight), (db if ctx.has_bias else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvLSTM layer over a whole sequence  (train/unet.py:21-36 x T, :55-57)
+# ---------------------------------------------------------------------------------------------
+class ConvLSTMSeq(torch.autograd.Function):
+    """All T steps of one ConvLSTM layer.
+
+    x_all bf16 [T,B,H,W,Cxp]; h0 bf16 [B,H,W,Hdp] / c0 f32 or None (zero state).
+    Returns (h_all bf16 [T,B,H,W,Hdp], c_T f32 [B,H,W,Hdp]); h_T is h_all[T-1].
+    Forward: one fused kernel per step (gate conv over (x_t, h_{t-1}) + nonlinearities + cell
+    update), post-activation gates kept in bf16 for the backward pass when training.
+    Backward: per step (reverse) a point-wise kernel + the h-part input-gradient GEMM; the x-part
+    input gradient and the weight gradient are batched over all T after the loop.
+    """
+
+    @staticmethod
+    def forward(ctx, x_all, h0, c0, weight, bias, Hd, Cx, need_grad):
+        ctx.set_materialize_grads(False)
+        _dev(x_all, BF16, "x_all")
+        T, B, H, W, Cxp = x_all.shape
+        Hdp = cpad(Hd)
+        dev = x_all.device
+        ks = weight.shape[-1]
+        pd = lstm_pack_desc(Hd, Cx, ks)
+        wp = pack_weights(pd, weight)
+        bp = pack_bias(pd, bias) if bias is not None else None
+        h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=BF16, device=dev)
+        c_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=F32, device=dev)
+        if h0 is None:
+            h_hist[0].zero_()
+        else:
+            h_hist[0].copy_(h0)
+        if c0 is not None:
+            c_hist[0].copy_(c0)
+        gates = torch.empty((T, B, H, W, 4, Hdp), dtype=BF16, device=dev) if need_grad else None
+        for t in range(T):
+            igemm_lstm(x_all[t], h_hist[t], wp, bp, c_hist[t] if (c0 is not None or t > 0) else None, c_hist[t + 1], h_hist[t + 1],
+                       gates[t] if need_grad else None, ks)
+        if need_grad:
+            ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates)
+            ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
+        return h_hist[1:], c_hist[T]
+
+    @staticmethod
+    def backward(ctx, dh_all, dc_T):
+        x_all, weight, h_hist, c_hist, gates = ctx.saved_tensors
+        Hd, Cx, has_c0, has_bias, ks = ctx.cfg
+        T, B, H, W, Cxp = x_all.shape
+        Hdp = cpad(Hd)
+        dev = x_all.device
+        pixels = B * H * W
+        dh_all = None if dh_all is None else dh_all.contiguous()
+        dgates = torch.empty((T, B, H, W, 4 * Hdp), dtype=BF16, device=dev)
+        dc = torch.empty((B, H, W, Hdp), dtype=F32, device=dev)
+        dc_zero = dc_T is None
+        if not dc_zero:
+            dc.copy_(dc_T)
+        ddh = lstm_dgrad_pack_desc(Hd, Cx, Hd, ks)
+        wd_h = pack_weights(ddh, weight, Cx * ks * ks)
+        dh_rec = None
+        buf = [torch.empty((B, H, W, Hdp), dtype=BF16, device=dev) for _ in range(2)]
+        need_h0 = ctx.needs_input_grad[1]
+        for t in range(T - 1, -1, -1):
+            c_prev = c_hist[t] if (has_c0 or t > 0) else None
+            L.check(L.lib.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
+                                                    _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec), _p(dc),
+                                                    int(dc_zero), _p(dgates[t]), pixels, Hdp, _stream()), "lstm_bwd_pointwise")
+            dc_zero = False
+            if t > 0 or need_h0:
+                dh_rec = buf[t & 1]
+                igemm_store([SrcView(dgates[t])], wd_h, (H, W), B, [(dh_rec, 0, ddh.N, 0, 1, 0, 0)], ktap=ks, pad=ks // 2)
+        dg_flat = dgates.view(T * B, H, W, 4 * Hdp)
+        x_flat = x_all.reshape(T * B, H, W, Cxp)
+        hprev_flat = h_hist[:T].reshape(T * B, H, W, Hdp)
+        ud = lstm_wgrad_unpack_desc(Hd, Cx, ks)
+        dwp = igemm_wgrad([SrcView(x_flat), SrcView(hprev_flat)], [(dg_flat, 0, 4 * Hdp, 0, 1, 0, 0)], ud.N, ud.Ktot, (H, W), T * B,
+                          ktap=ks, pad=ks // 2)
+        dweight = unpack_wgrad(ud, dwp, weight)
+        dbias = None
+        if has_bias:
+            cs = colsum(dg_flat).view(4, Hdp)[:, :Hd]
+            dbias = cs.reshape(4 * Hd).contiguous()
+        dx_all = None
+        if ctx.needs_input_grad[0]:
+            ddx = lstm_dgrad_pack_desc(Hd, Cx, Cx, ks)
+            wd_x = pack_weights(ddx, weight, 0)
+            dx_all = torch.empty_like(x_all)
+            igemm_store([SrcView(dg_flat)], wd_x, (H, W), T * B, [(dx_all.view(T * B, H, W, Cxp), 0, ddx.N, 0, 1, 0, 0)], ktap=ks,
+                        pad=ks // 2)
+        dh0 = dh_rec if need_h0 else None
+        dc0 = dc if (has_c0 and ctx.needs_input_grad[2]) else None
+        return dx_all, dh0, dc0, dweight, dbias, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# Loss (main.py:28-72)
+# ---------------------------------------------------------------------------------------------
+class LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y, mask, use_mask):
+        _dev(y_pred, F32, "y_pred")
+        y = _dev(y.contiguous(), F32, "y")
+        H, W = y_pred.shape[-2], y_pred.shape[-1]
+        planes = y_pred.numel() // (H * W)
+        m = _dev(mask.contiguous().float(), F32, "mask") if (use_mask and mask is not None) else None
+        sums = torch.zeros((4,), dtype=torch.float64, device=y_pred.device)
+        L.check(L.lib.uclstm_loss_fwd(_p(y_pred), _p(y), _p(m), _p(sums), planes, H, W, _stream()), "loss_fwd")
+        n1 = float(y_pred.numel())
+        n2 = float(planes * (H - 1) * (W - 1))
+        if m is not None:
+            d1 = sums[1] + 1e-8
+            d2 = sums[3] + 1e-8
+        else:
+            d1 = torch.full((), n1, dtype=torch.float64, device=y_pred.device)
+            d2 = torch.full((), n2, dtype=torch.float64, device=y_pred.device)
+        loss = (sums[0] / d1 + 0.005 * sums[2] / d2).float()
+        ctx.save_for_backward(y_pred, y, m, (1.0 / d1).float(), (0.005 / d2).float())
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        y_pred, y, m, c1, c2 = ctx.saved_tensors
+        H, W = y_pred.shape[-2], y_pred.shape[-1]
+        planes = y_pred.numel() // (H * W)
+        grad = torch.empty_like(y_pred)
+        coefs = torch.stack((c1 * g, c2 * g)).float().contiguous()      # stays on device: no host sync in the step
+        L.check(L.lib.uclstm_loss_bwd(_p(y_pred), _p(y), _p(m), _p(coefs), _p(grad), planes, H, W, _stream()), "loss_bwd")
+        return grad, None, None, None

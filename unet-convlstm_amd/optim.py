@@ -1,0 +1,98 @@
+"""Flat-buffer AdamW with fused global-norm clipping (reference step: main.py:106-108, optimiser main.py:275).
+
+``FlatParams`` re-homes a module's parameters and gradients into two contiguous f32 buffers
+(device-agnostic, pure bookkeeping) so that (a) the optimiser is two kernels -- a sum-of-squares
+reduction and one AdamW sweep that reads the clip coefficient on device, no host sync -- and
+(b) data-parallel gradient exchange works on contiguous slices (``ddp.FlatDDP``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional
+
+import torch
+
+
+class FlatParams:
+    """Parameters and their gradients as views into two flat f32 buffers (registration order)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatParams: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if dt != torch.float32 or any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatParams: all parameters must be float32 on one device")
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.numel = off
+        self.flat_p = torch.empty(off, dtype=dt, device=dev)
+        self.flat_g = torch.zeros(off, dtype=dt, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+        self.attach_grads()
+
+    def attach_grads(self) -> None:
+        """(Re)point every ``.grad`` at its slice of the flat buffer (autograd then accumulates in place)."""
+        for p, o in zip(self.params, self.offsets):
+            g = self.flat_g[o:o + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+        self.attach_grads()
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """AdamW(lr, betas, eps, weight_decay) + optional ``clip_grad_norm_(max_grad_norm)`` in two HIP kernels.
+
+    Semantics equal ``torch.nn.utils.clip_grad_norm_(params, max_grad_norm)`` followed by
+    ``torch.optim.AdamW.step()`` (main.py:106-108).  ``zero_grad`` keeps gradients as views of the
+    flat buffer (``set_to_none`` is accepted and ignored).
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm: Optional[float] = None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdamW supports a single parameter group")
+        self.flat = FlatParams(self.param_groups[0]["params"])
+        if not self.flat.flat_p.is_cuda:
+            raise RuntimeError("FusedAdamW needs HIP device parameters (no CPU path)")
+        self.m = torch.zeros_like(self.flat.flat_p)
+        self.v = torch.zeros_like(self.flat.flat_p)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.flat.flat_p.device)
+        self.max_grad_norm = max_grad_norm
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 - signature parity with torch
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the last clipped step's gradients (device scalar, f64)."""
+        return self.sumsq.sqrt()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib as L
+        from .ops import _stream
+        assert closure is None
+        g = self.param_groups[0]
+        f = self.flat
+        f.attach_grads()
+        self.step_count += 1
+        sq = None
+        if self.max_grad_norm is not None:
+            self.sumsq.zero_()
+            L.check(L.lib.uclstm_sumsq(C.c_void_p(f.flat_g.data_ptr()), f.numel, C.c_void_p(self.sumsq.data_ptr()), _stream()), "sumsq")
+            sq = C.c_void_p(self.sumsq.data_ptr())
+        L.check(L.lib.uclstm_adamw_step(C.c_void_p(f.flat_p.data_ptr()), C.c_void_p(self.m.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                        C.c_void_p(f.flat_g.data_ptr()), f.numel, sq,
+                                        float(self.max_grad_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                        float(g["eps"]), float(g["weight_decay"]), self.step_count, _stream()), "adamw_step")
+        return None
