@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training frames/sec of the UNet-ConvLSTM path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], reference hyper-parameters main.py:215-228): TemporalUNetDualView(
+base_ch=64, use_skip_lstm=True), per-GPU batch 32 sequences of 20 frames 64x64x2, synthetic data resident
+in HBM, random-init weights.  A step = zero_grad -> forward -> loss -> backward -> gradient all-reduce ->
+clip(1.0) -> AdamW (main.py:91-108), bf16 MFMA compute with f32 accumulation and f32 master weights.
+Weak scaling: per-GPU batch fixed, sequences sharded over ranks, one RCCL gradient exchange per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      -- dominant MFMA kernel: algorithmic FLOPs / HIP-event time of its launches (one instrumented step)
+  cpu_baseline  -- the CPU oracle's training step timed on this host's cores on a bounded sample (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+TRAIN_GFLOP_PER_FRAME = {(64, True, 64): 39.79, (32, False, 64): 6.33, (64, True, 128): 159.17}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU (main.py:215)")
+    ap.add_argument("--seq", type=int, default=20)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--base-ch", type=int, default=64)
+    ap.add_argument("--no-skip-lstm", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(base_ch: int, skip: bool, size: int):
+    """Oracle (CPU restatement, kind 'port') training step on the host cores, bounded sample."""
+    from oracle import unet_oracle as O
+    import unet_convlstm_amd as U
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = U.TemporalUNetDualView(1, 1, base_ch=base_ch, use_skip_lstm=skip)          # parameter container only (CPU)
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    B, T = 2, 4
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((B, T, 2, size, size), generator=g)
+    y = torch.rand((B, T, 1, size, size), generator=g) * 2 - 1
+    O.train_step({k: v for k, v in p.items()}, x[:1, :1], y[:1, :1], None, False)      # thread-pool / allocator warm-up
+    t0 = time.perf_counter()
+    O.train_step(p, x, y, None, False)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 oracle training step (fp32 PyTorch eager CPU), B={B} T={T} {size}x{size}, base_ch={base_ch}, "
+                      f"skip_lstm={skip}; {dt:.1f} s"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import unet_convlstm_amd as U
+    from unet_convlstm_amd import ops
+
+    skip = not a.no_skip_lstm
+    torch.manual_seed(1234)
+    model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
+    opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    ddp = U.FlatDDP(model, opt.flat) if world > 1 else None
+    data = U.SyntheticSequences(a.batch, a.seq, a.size, a.size, seed=1 + rank, kind="uniform", device=dev)
+    x, y = data.x, data.y
+
+    def step():
+        return U.train_step(model, opt, x, y, None, False, ddp)      # USE_MASK = False, main.py:219
+
+    log(f"model + data ready ({sum(p.numel() for p in model.parameters())} parameters); warm-up x{a.warmup}")
+    for i in range(a.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    frames = a.batch * a.seq * world * a.steps
+    value = frames / dt
+    log(f"timed {a.steps} steps in {dt:.3f} s")
+    lossv = float(loss)
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, e0, e1 in ops.PROFILE:
+            t_ms = e0.elapsed_time(e1)
+            k = agg.setdefault(kind, [0.0, 0.0, 0])
+            k[0] += flops
+            k[1] += t_ms
+            k[2] += 1
+        ops.PROFILE = None
+        if agg:
+            dom = max(agg, key=lambda k: agg[k][1])
+            fl, ms, n = agg[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                    "avg_launch_ms": round(ms / n, 4),
+                    "all": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
+                            for k, v in agg.items()}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        gf = TRAIN_GFLOP_PER_FRAME.get((a.base_ch, skip, a.size))
+        out = {
+            "metric": "training frames/sec, Moving-MNIST 64x64 seq-20",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) train step, "
+                                   f"{a.size}x{a.size} seq-{a.seq}, per-GPU batch {a.batch}, AdamW+clip",
+                       "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
+            "final_loss": round(lossv, 5),
+        }
+        if gf is not None:
+            out["model_tflops"] = round(value * gf / 1e3, 2)
+            out["model_mfma_frac"] = round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -242,6 +242,8 @@ int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* g, int64_t 
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);
 const char* uclstm_build_arch(void);
+/* hipGetErrorString of the most recent launch that returned UCLSTM_E_LAUNCH. */
+const char* uclstm_last_error_string(void);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,46 @@ BN_MOMENTUM = 0.1    # idem
 
 
 # ---------------------------------------------------------------------------
+# Optional storage-precision emulation (checker-side tool, off by default)
+# ---------------------------------------------------------------------------
+# The HIP path stores activations and weight panels in bf16 and accumulates in
+# f32.  Inside ``with bf16_storage():`` the oracle rounds to bf16 at exactly the
+# points where the kernels store (conv/convT outputs, BN+ReLU outputs, LSTM h,
+# weights, the network input) and is otherwise unchanged f32 arithmetic.  The
+# rounding is straight-through for autograd, i.e. gradients are the exact f32
+# gradients of a network that has the kernel's forward activations (and hence
+# the kernel's ReLU masks).  This separates "is the kernel arithmetic right"
+# (tight tolerance against this mode) from "how far does bf16 storage drift
+# from the f32 reference" (stated tolerance against the plain oracle).
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+_EMULATE = False
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _EMULATE
+        self._old = _EMULATE
+        _EMULATE = True
+
+    def __exit__(self, *exc):
+        global _EMULATE
+        _EMULATE = self._old
+
+
+def _q(t: Tensor) -> Tensor:
+    return _RoundSTE.apply(t) if _EMULATE else t
+
+
+# ---------------------------------------------------------------------------
 # ConvLSTM (train/unet.py:14-60)
 # ---------------------------------------------------------------------------
 def convlstm_cell(x: Tensor, h: Optional[Tensor], c: Optional[Tensor],
@@ -45,14 +85,14 @@ def convlstm_cell(x: Tensor, h: Optional[Tensor], c: Optional[Tensor],
     if h is None:
         h = x.new_zeros(B, hd, H, W)
         c = x.new_zeros(B, hd, H, W)
-    pre = F.conv2d(torch.cat((x, h), dim=1), weight, bias, padding=k // 2)
+    pre = F.conv2d(torch.cat((_q(x), _q(h)), dim=1), _q(weight), bias, padding=k // 2)
     pi, pf, pg, po = pre[:, 0:hd], pre[:, hd:2 * hd], pre[:, 2 * hd:3 * hd], pre[:, 3 * hd:4 * hd]
     gi = 1.0 / (1.0 + torch.exp(-pi))
     gf = 1.0 / (1.0 + torch.exp(-pf))
     gg = torch.tanh(pg)
     go = 1.0 / (1.0 + torch.exp(-po))
     c_new = gf * c + gi * gg            # :34
-    h_new = go * torch.tanh(c_new)      # :35
+    h_new = _q(go * torch.tanh(c_new))  # :35
     return h_new, c_new
 
 
@@ -94,6 +134,7 @@ def batchnorm_relu(z: Tensor, p: Params, prefix: str, training: bool,
     """
     gamma, beta = p[f"{prefix}.weight"], p[f"{prefix}.bias"]
     if training:
+        z = _q(z)         # the HIP path stores the conv output before normalising it
         n = z.shape[0] * z.shape[2] * z.shape[3]
         mean = z.mean(dim=(0, 2, 3))
         var = ((z - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
@@ -109,15 +150,15 @@ def batchnorm_relu(z: Tensor, p: Params, prefix: str, training: bool,
         src = p if buffers_out is None else {**p, **buffers_out}
         mean, var = src[f"{prefix}.running_mean"], src[f"{prefix}.running_var"]
     xhat = (z - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
-    return torch.clamp_min(xhat * gamma[None, :, None, None] + beta[None, :, None, None], 0.0)
+    return _q(torch.clamp_min(xhat * gamma[None, :, None, None] + beta[None, :, None, None], 0.0))
 
 
 def double_conv(x: Tensor, p: Params, prefix: str, training: bool,
                 buffers_out: Optional[Params]) -> Tensor:
     """(conv3x3 pad1 + bias -> BN -> ReLU) x2, train/unet.py:66-75 (Sequential indices 0,1,3,4)."""
-    z = F.conv2d(x, p[f"{prefix}.net.0.weight"], p[f"{prefix}.net.0.bias"], padding=1)
+    z = F.conv2d(_q(x), _q(p[f"{prefix}.net.0.weight"]), p[f"{prefix}.net.0.bias"], padding=1)
     a = batchnorm_relu(z, p, f"{prefix}.net.1", training, buffers_out)
-    z = F.conv2d(a, p[f"{prefix}.net.3.weight"], p[f"{prefix}.net.3.bias"], padding=1)
+    z = F.conv2d(a, _q(p[f"{prefix}.net.3.weight"]), p[f"{prefix}.net.3.bias"], padding=1)
     return batchnorm_relu(z, p, f"{prefix}.net.4", training, buffers_out)
 
 
@@ -128,7 +169,7 @@ def down(x: Tensor, p: Params, prefix: str, training: bool, buffers_out) -> Tens
 
 def up(x1: Tensor, x2: Tensor, p: Params, prefix: str, training: bool, buffers_out) -> Tensor:
     """ConvTranspose2d(k2,s2) -> pad to skip size -> cat([skip, up]) -> DoubleConv, train/unet.py:87-98."""
-    u = F.conv_transpose2d(x1, p[f"{prefix}.up.weight"], p[f"{prefix}.up.bias"], stride=2)
+    u = _q(F.conv_transpose2d(_q(x1), _q(p[f"{prefix}.up.weight"]), p[f"{prefix}.up.bias"], stride=2))
     dy = x2.shape[2] - u.shape[2]
     dx = x2.shape[3] - u.shape[3]
     u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])     # :95-97
@@ -137,7 +178,7 @@ def up(x1: Tensor, x2: Tensor, p: Params, prefix: str, training: bool, buffers_o
 
 def out_conv(x: Tensor, p: Params, prefix: str) -> Tensor:
     """1x1 convolution, train/unet.py:101-107."""
-    return F.conv2d(x, p[f"{prefix}.conv.weight"], p[f"{prefix}.conv.bias"])
+    return F.conv2d(_q(x), p[f"{prefix}.conv.weight"], p[f"{prefix}.conv.bias"])
 
 
 def spatial_attention(x: Tensor, p: Params, prefix: str) -> Tensor:

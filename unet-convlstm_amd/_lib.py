@@ -9,6 +9,11 @@ import ctypes as C
 import os
 import re
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; libuclstm.so NEEDs the same SONAME.  torch must be loaded FIRST so that
+# the dynamic linker resolves our dependency to the runtime torch already uses -- otherwise the process holds two HIP
+# runtimes and launches on torch's device pointers fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401  (load order matters, see above)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
@@ -100,8 +105,9 @@ _PROTOS = {
     "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
     "uclstm_abi_version": [],
     "uclstm_build_arch": [],
+    "uclstm_last_error_string": [],
 }
-_RESTYPES = {"uclstm_build_arch": C.c_char_p}
+_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_char_p}
 
 
 def header_symbols() -> list[str]:
@@ -134,4 +140,5 @@ lib = _load()
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise UclstmError(f"{what}: {_ERRORS.get(rc, 'error')} (code {rc})")
+        detail = f" [{lib.uclstm_last_error_string().decode()}]" if rc == -2 else ""
+        raise UclstmError(f"{what}: {_ERRORS.get(rc, 'error')} (code {rc}){detail}")

@@ -12,10 +12,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define UCLSTM_WAVE 64
 
-#define UCLSTM_CHECK_LAUNCH()                                   \
+// Launch and report only THIS launch's error: the per-thread "last error" may hold a stale, already
+// handled code from another library's HIP call (observed: a launch right after torch's own copies).
+inline int g_uclstm_last_hip_error = 0;      // hipError_t of the most recent failed launch (diagnostics)
+#define UCLSTM_LAUNCH(...)                                      \
     do {                                                        \
-        hipError_t e__ = hipGetLastError();                     \
-        if (e__ != hipSuccess) return UCLSTM_E_LAUNCH;          \
+        (void)hipGetLastError();                                \
+        hipLaunchKernelGGL(__VA_ARGS__);                        \
+        const hipError_t e__ = hipGetLastError();               \
+        if (e__ != hipSuccess) {                                \
+            g_uclstm_last_hip_error = (int)e__;                 \
+            return UCLSTM_E_LAUNCH;                             \
+        }                                                       \
     } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16 v) { return (float)v; }

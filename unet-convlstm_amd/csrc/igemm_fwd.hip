@@ -343,9 +343,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (d.epi == UCLSTM_EPI_LSTM)
-        hipLaunchKernelGGL(igemm_fwd_kernel<UCLSTM_EPI_LSTM>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
+        UCLSTM_LAUNCH(igemm_fwd_kernel<UCLSTM_EPI_LSTM>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
     else
-        hipLaunchKernelGGL(igemm_fwd_kernel<UCLSTM_EPI_STORE>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
-    UCLSTM_CHECK_LAUNCH();
+        UCLSTM_LAUNCH(igemm_fwd_kernel<UCLSTM_EPI_STORE>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
     return UCLSTM_OK;
 }

@@ -238,7 +238,6 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
         (void)hipFuncSetAttribute((const void*)igemm_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL(igemm_wgrad_kernel, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, (hipStream_t)stream, d, dv);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(igemm_wgrad_kernel, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, (hipStream_t)stream, d, dv);
     return UCLSTM_OK;
 }

@@ -145,9 +145,8 @@ extern "C" int32_t uclstm_loss_fwd(const float* y_pred, const float* y, const fl
     if (!y_pred || !y || !sums || planes <= 0 || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
     const int64_t total = planes * H * W;
     if (total >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid_for(total, 1024)), dim3(NT), 0, (hipStream_t)stream, y_pred, y, mask, sums, total,
+    UCLSTM_LAUNCH(loss_fwd_kernel, dim3(grid_for(total, 1024)), dim3(NT), 0, (hipStream_t)stream, y_pred, y, mask, sums, total,
                        make_fastdiv(H * W), make_fastdiv(W), H, W);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -156,16 +155,14 @@ extern "C" int32_t uclstm_loss_bwd(const float* y_pred, const float* y, const fl
     if (!y_pred || !y || !grad || !coefs || planes <= 0 || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
     const int64_t total = planes * H * W;
     if (total >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(total, 2048)), dim3(NT), 0, (hipStream_t)stream, y_pred, y, mask, coefs, grad,
+    UCLSTM_LAUNCH(loss_bwd_kernel, dim3(grid_for(total, 2048)), dim3(NT), 0, (hipStream_t)stream, y_pred, y, mask, coefs, grad,
                        total, make_fastdiv(H * W), make_fastdiv(W), H, W);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_sumsq(const float* g, int64_t n, double* out, void* stream) {
     if (!g || !out || n <= 0 || ((uintptr_t)g % 16)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((n + 3) / 4, 1024)), dim3(NT), 0, (hipStream_t)stream, g, n, out);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(sumsq_kernel, dim3(grid_for((n + 3) / 4, 1024)), dim3(NT), 0, (hipStream_t)stream, g, n, out);
     return UCLSTM_OK;
 }
 
@@ -174,11 +171,11 @@ extern "C" int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* 
     if (!p || !m || !v || !g || n <= 0 || step < 1) return UCLSTM_E_BADARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
+    UCLSTM_LAUNCH(adamw_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_abi_version(void) { return UCLSTM_ABI_VERSION; }
 extern "C" const char* uclstm_build_arch(void) { return "gfx950"; }
+extern "C" const char* uclstm_last_error_string(void) { return hipGetErrorString((hipError_t)g_uclstm_last_hip_error); }

@@ -110,21 +110,18 @@ int grid_for(int64_t total) {
 
 extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream) {
     if (!desc_ok(d) || !w || !wp) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, w, (bf16*)wp);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, w, (bf16*)wp);
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, float* grad, int32_t accumulate, void* stream) {
     if (!desc_ok(d) || !dwp || !grad) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, dwp, grad, accumulate);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, dwp, grad, accumulate);
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, void* stream) {
     if (!desc_ok(d) || !b || !bp) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(pack_bias_kernel, dim3((d->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, b, bp);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(pack_bias_kernel, dim3((d->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, b, bp);
     return UCLSTM_OK;
 }

@@ -549,9 +549,8 @@ extern "C" int32_t uclstm_bn_finalize(const float* stats, int32_t groups, int32_
     if (stats && (tiles_per_group <= 0 || count_per_group <= 0)) return UCLSTM_E_BADARG;
     const double inv = stats ? 1.0 / (double)count_per_group : 0.0;
     const double unb = (stats && count_per_group > 1) ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C,
+    UCLSTM_LAUNCH(bn_finalize_kernel, dim3((Cp + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C,
                        inv, unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -561,9 +560,8 @@ extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* sca
         return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (uint4*)a, scale,
+    UCLSTM_LAUNCH(bn_apply_relu_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (uint4*)a, scale,
                        shift, chunks, make_fastdiv(Cp / 8), make_fastdiv((uint32_t)pixels_per_group), Cp);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -581,9 +579,8 @@ extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const flo
     if (bpg < 1) bpg = 1;
     const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
+    UCLSTM_LAUNCH(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, sums, pixels_per_group, Cp, cg, bpg, ppb);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -595,10 +592,9 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
         return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
+    UCLSTM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, sums, (uint4*)dz, chunks, make_fastdiv(Cp / 8),
                        make_fastdiv((uint32_t)pixels_per_group), Cp, (float)(1.0 / (double)pixels_per_group));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -607,9 +603,8 @@ extern "C" int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, in
     const int Ho = H / 2, Wo = W / 2;
     const int64_t chunks = (int64_t)n_img * Ho * Wo * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (uint4*)p, chunks,
+    UCLSTM_LAUNCH(maxpool_fwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (uint4*)p, chunks,
                        make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -619,9 +614,8 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, 
     const int Ho = H / 2, Wo = W / 2;
     const int64_t chunks = (int64_t)n_img * Ho * Wo * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)dp,
+    UCLSTM_LAUNCH(maxpool_bwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)dp,
                        (uint4*)da, chunks, make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -633,9 +627,8 @@ extern "C" int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_p
     if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Hd_p / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
+    UCLSTM_LAUNCH(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
                        (const uint4*)dh_a, (const uint4*)dh_b, dc_io, dc_is_zero, (uint4*)dgates, chunks, make_fastdiv(Hd_p / 8));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -645,9 +638,8 @@ extern "C" int32_t uclstm_nchw_to_nhwc(const float* x, void* out, int32_t n_img,
         return UCLSTM_E_BADARG;
     const int64_t items = (int64_t)n_img * (Cp / 8) * H * W;
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Cp / 8,
+    UCLSTM_LAUNCH(nchw_to_nhwc_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Cp / 8,
                        make_fastdiv(H * W), make_fastdiv(Cp / 8), make_fastdiv(inner), inner_stride, outer_stride);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -661,9 +653,8 @@ extern "C" int32_t uclstm_nhwc_to_nchw(const void* a, float* out, int32_t n_img,
     if (!aligned16(a) || !out || n_img <= 0 || C <= 0 || Cp < C || (Cp % 8) || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
     const int64_t items = (int64_t)n_img * (Cp / 8) * H * W;
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, out, items, C, Cp / 8,
+    UCLSTM_LAUNCH(nhwc_to_nchw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, out, items, C, Cp / 8,
                        make_fastdiv(H * W), make_fastdiv(Cp / 8));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -672,9 +663,8 @@ extern "C" int32_t uclstm_nchw_to_nhwc_f32(const float* x, float* out, int32_t n
     if (!x || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
     const int64_t items = (int64_t)n_img * Cp * H * W;
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, out, items, C, Cp,
+    UCLSTM_LAUNCH(nchw_to_nhwc_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, out, items, C, Cp,
                        make_fastdiv(H * W), make_fastdiv(Cp));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -683,9 +673,8 @@ extern "C" int32_t uclstm_nhwc_to_nchw_f32(const float* a, float* out, int32_t n
     if (!a || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
     const int64_t items = (int64_t)n_img * C * H * W;
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, a, out, items, C, Cp,
+    UCLSTM_LAUNCH(nhwc_to_nchw_f32_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, a, out, items, C, Cp,
                        make_fastdiv(H * W), make_fastdiv(C));
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -695,10 +684,9 @@ extern "C" int32_t uclstm_im2col3x3_first(const float* x, void* out, int32_t n_i
         return UCLSTM_E_BADARG;
     const int64_t items = (int64_t)n_img * (Kp / 8) * H * W;
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(im2col_first_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Kp / 8, H, W,
+    UCLSTM_LAUNCH(im2col_first_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, x, (uint4*)out, items, C, Kp / 8, H, W,
                        make_fastdiv(H * W), make_fastdiv(W), make_fastdiv(Kp / 8), make_fastdiv(inner), make_fastdiv(C), inner_stride,
                        outer_stride);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -707,9 +695,8 @@ extern "C" int32_t uclstm_outconv_fwd(const void* a, const float* w, const float
     if (!aligned16(a) || !w || !y || n_img <= 0 || HW <= 0 || Cp < C || (Cp % 8) || C <= 0 || Co <= 0) return UCLSTM_E_BADARG;
     const int64_t pixels = n_img * HW;
     if (pixels >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    hipLaunchKernelGGL(outconv_fwd_kernel, dim3(ew_grid(pixels)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, w, b, y, pixels,
+    UCLSTM_LAUNCH(outconv_fwd_kernel, dim3(ew_grid(pixels)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, w, b, y, pixels,
                        make_fastdiv(HW), Cp / 8, C, Co);
-    UCLSTM_CHECK_LAUNCH();
     return UCLSTM_OK;
 }
 
@@ -722,9 +709,8 @@ extern "C" int32_t uclstm_outconv_bwd(const void* a, const float* w, const float
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     if (da) {
         if (!aligned16(da)) return UCLSTM_E_BADARG;
-        hipLaunchKernelGGL(outconv_bwd_da_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, w, dy, (uint4*)da, chunks,
+        UCLSTM_LAUNCH(outconv_bwd_da_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, w, dy, (uint4*)da, chunks,
                            make_fastdiv(Cp / 8), make_fastdiv(HW), C, Co);
-        UCLSTM_CHECK_LAUNCH();
     }
     if (dw && db) {
         const ColGeom cg = col_geom(Cp);
@@ -732,9 +718,8 @@ extern "C" int32_t uclstm_outconv_bwd(const void* a, const float* w, const float
         if (nb > 1024) nb = 1024;
         const int64_t ppb = (pixels + nb - 1) / nb;
         const size_t lds = (size_t)cg.rows * (cg.cpc * 8 + 1) * sizeof(float);
-        hipLaunchKernelGGL(outconv_bwd_dw_kernel, dim3(nb, Co), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, dy, dw, db, pixels,
+        UCLSTM_LAUNCH(outconv_bwd_dw_kernel, dim3(nb, Co), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, dy, dw, db, pixels,
                            make_fastdiv(HW), cg, C, Co, ppb);
-        UCLSTM_CHECK_LAUNCH();
     }
     return UCLSTM_OK;
 }
@@ -746,7 +731,6 @@ extern "C" int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int3
     if (nb > 1024) nb = 1024;
     const int64_t ppb = (pixels + nb - 1) / nb;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 8 * sizeof(float);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
-    UCLSTM_CHECK_LAUNCH();
+    UCLSTM_LAUNCH(colsum_kernel, dim3(nb), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
     return UCLSTM_OK;
 }

@@ -45,6 +45,23 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# Optional per-launch timing of the MFMA kernels (bench.py's roofline leg): when PROFILE is a list every GEMM launch
+# is bracketed by HIP events on the launch stream and (kernel, algorithmic flops, start, stop) is appended.
+PROFILE: Optional[list] = None
+
+
+def _timed(kind: str, flops: float, launch) -> None:
+    if PROFILE is None:
+        launch()
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE.append((kind, flops, e0, e1))
+
+
 # ---------------------------------------------------------------------------------------------
 # descriptors
 # ---------------------------------------------------------------------------------------------
@@ -229,7 +246,8 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
     for i, sg in enumerate(segs):
         _fill_seg(d.seg[i], *sg)
     d.stats = None if stats is None else stats.data_ptr()
-    L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)")
+    flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
+    _timed("igemm_fwd_store", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"))
 
 
 def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
@@ -247,7 +265,8 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
     d.c_prev = None if c_prev is None else c_prev.data_ptr()
     d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
-    L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)")
+    flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * (x.shape[3] + h_prev.shape[3])
+    _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"))
 
 
 def wgrad_splits(n_tiles: int, pixels: int) -> int:
@@ -274,7 +293,8 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     n_tiles = ((N + 127) // 128) * taps * sum((s.t.shape[3] + 127) // 128 for s in srcs)
     d.splits = wgrad_splits(n_tiles, n_img * out_hw[0] * out_hw[1])
     d.accumulate = 1
-    L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad")
+    flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
+    _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"))
     return dwp
 
 
