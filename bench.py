@@ -55,11 +55,13 @@ def cpu_baseline(base_ch: int, skip: bool, size: int):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)          # a 1-GPU box owns a 16-core share of the host; more threads only oversubscribe it
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = U.TemporalUNetDualView(1, 1, base_ch=base_ch, use_skip_lstm=skip)          # parameter container only (CPU)
     p = {k: v.detach().clone() for k, v in m.state_dict().items()}
     B, T = 2, 4
+    log(f"cpu_baseline: oracle training step on {cores} host threads, B={B} T={T} ...")
     g = torch.Generator().manual_seed(1)
     x = torch.rand((B, T, 2, size, size), generator=g)
     y = torch.rand((B, T, 1, size, size), generator=g) * 2 - 1

@@ -1,0 +1,250 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/uclstm.h, argument contracts are
+enforced before any launch, the host-side mirror keeps the reference's module surface, and the flat-buffer
+data-parallel path is correct with world_size 2 on gloo.  No kernel is launched here."""
+import ctypes as C
+import inspect
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, sub
+
+import unet_convlstm_amd as U
+from unet_convlstm_amd import _lib as L
+from unet_convlstm_amd import ops
+from unet_convlstm_amd.optim import FlatParams
+from unet_convlstm_amd.ddp import FlatDDP
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------
+def test_library_exports_every_header_symbol():
+    syms = L.header_symbols()
+    assert len(syms) >= 29
+    assert set(syms) == set(L._PROTOS), (set(syms) ^ set(L._PROTOS))
+    raw = C.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), s
+    assert L.lib.uclstm_abi_version() == 1
+    assert L.lib.uclstm_build_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_the_header():
+    # sizes follow from the header's field lists (natural alignment, 8-byte pointers)
+    assert C.sizeof(L.Src) == 32
+    assert C.sizeof(L.Seg) == 48
+    assert C.sizeof(L.PackDesc) == 4 * 17 + 4 + 8 * 4      # 17 ints (+4 pad) + 4 int64
+    d = L.IgemmDesc()
+    assert C.sizeof(d) % 8 == 0 and type(d).src.offset == 32 and type(d).wp.offset == 96
+
+
+def test_argument_contracts_are_checked_before_launch():
+    # null / malformed descriptors must come back as UCLSTM_E_BADARG (-1) without touching a device
+    assert L.lib.uclstm_igemm_fwd(None, None) == -1
+    assert L.lib.uclstm_igemm_wgrad(None, None) == -1
+    d = L.IgemmDesc()
+    d.n_img, d.H, d.W, d.groups, d.ktap, d.scale, d.pad, d.nsrc = 4, 8, 8, 3, 3, 1, 1, 1      # 4 % 3 != 0
+    assert L.lib.uclstm_igemm_fwd(C.byref(d), None) == -1
+    assert L.lib.uclstm_igemm_tiles_per_group(4, 8, 8, 3) == -1
+    assert L.lib.uclstm_igemm_tiles_per_group(640, 64, 64, 20) == 1024
+    assert L.lib.uclstm_bn_apply_relu(None, None, None, None, 10, 10, 8, None) == -1
+    assert L.lib.uclstm_maxpool2_fwd(None, None, 1, 4, 4, 8, None) == -1
+    assert L.lib.uclstm_adamw_step(None, None, None, None, 10, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
+    pd = ops.conv_pack_desc(8, 8, [8], [8])
+    pd.Ktot += 64
+    assert L.lib.uclstm_pack_weights(C.byref(pd), None, None, None) == -1
+    with pytest.raises(L.UclstmError):
+        L.check(-1, "x")
+
+
+def test_pack_descriptors_geometry():
+    d = ops.conv_pack_desc(40, 24 + 8, [24, 8], [24, 8])
+    assert (d.N, d.taps, d.kseg[0], d.kseg[1], d.Ktot) == (40, 9, 64, 64, 9 * 128)
+    assert (d.choff[0], d.choff[1], d.stride_n, d.stride_k) == (0, 24, 32 * 9, 9)
+    d = ops.lstm_pack_desc(1024, 1024)
+    assert (d.N, d.Ktot, d.n_mode) == (4096, 9 * 2048, L.NMODE_LSTM)
+    d = ops.lstm_pack_desc(5, 4)
+    assert (d.N, d.kseg[0], d.kseg[1]) == (64, 64, 64)
+    d = ops.lstm_dgrad_pack_desc(5, 4, 5)
+    assert (d.N, d.kseg[0], d.k_hdp, d.k_hd, d.tap_flip) == (8, 64, 8, 5, 1)
+    d = ops.lstm_wgrad_unpack_desc(1024, 1024)
+    assert (d.N, d.Ktot, d.stride_ntap) == (4096, 9 * 2048, 1024 * 2048 * 9)
+    d = ops.convt_pack_desc(1024, 512)
+    assert (d.N, d.Ktot, d.n_cp, d.stride_n, d.stride_k, d.stride_ntap) == (2048, 1024, 512, 4, 2048, 1)
+    d = ops.convt_dgrad_pack_desc(1024, 512)
+    assert (d.N, d.taps, d.Ktot) == (1024, 4, 4 * 512)
+    d = ops.im2col_pack_desc(64, 2, 24)
+    assert (d.N, d.Ktot, d.k_mode, d.k_hd, d.k_hdp) == (64, 64, L.KMODE_IM2COL, 2, 9)
+    assert ops.wgrad_splits(9, 2621440) == 113 and ops.wgrad_splits(4608, 10240) == 1 and ops.wgrad_splits(1, 100) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# module surface
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("model_noskip", dict(base_ch=4, use_skip_lstm=False)),
+    ("model_skip", dict(base_ch=4, use_skip_lstm=True)),
+    ("model_2layer_att", dict(base_ch=2, lstm_layers=2, use_attention=True)),
+])
+def test_state_dict_keys_shapes_dtypes_equal_the_reference(name, kw):
+    ref = sub(load_golden(name), "p/")
+    m = U.TemporalUNetDualView(1, 1, **kw)
+    sd = m.state_dict()
+    assert list(sd.keys()) == sorted(sd.keys(), key=list(sd.keys()).index)       # deterministic
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k].shape) and v.dtype == ref[k].dtype, k
+    m.load_state_dict(ref, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k              # bit-exact round trip of the reference layout
+
+
+def test_constructor_signatures_and_public_attributes():
+    def params(cls):
+        return [(p.name, p.default) for p in list(inspect.signature(cls.__init__).parameters.values())[1:]]
+    assert params(U.ConvLSTMCell) == [("input_dim", inspect._empty), ("hidden_dim", inspect._empty), ("kernel_size", 3), ("bias", True)]
+    assert params(U.ConvLSTM) == [("input_dim", inspect._empty), ("hidden_dim", inspect._empty), ("num_layers", 1), ("kernel_size", 3)]
+    assert params(U.DoubleConv) == params(U.Down) == params(U.Up) == params(U.OutConv) == [("in_ch", inspect._empty), ("out_ch", inspect._empty)]
+    assert params(U.SpatialAttention) == [("kernel_size", 7)]
+    assert params(U.TemporalUNetDualView) == [("in_channels_per_sat", 1), ("out_channels", 1), ("base_ch", 32), ("lstm_layers", 1),
+                                             ("use_skip_lstm", False), ("use_attention", False)]
+    cell = U.ConvLSTMCell(3, 5)
+    assert cell.hidden_dim == 5 and isinstance(cell.conv, torch.nn.Conv2d) and cell.conv.weight.shape == (20, 8, 3, 3)
+    lstm = U.ConvLSTM(3, 5, num_layers=2)
+    assert len(lstm.layers) == 2 and lstm.layers[1].conv.in_channels == 10
+    m = U.TemporalUNetDualView(use_skip_lstm=True)
+    assert m.use_skip_lstm and not m.use_attention and callable(m.encode_once) and U.UNet is U.TemporalUNetDualView
+    up = U.Up(16, 8)
+    assert up.up.weight.shape == (16, 8, 2, 2)
+
+
+def test_same_seed_gives_the_reference_initialisation():
+    """Parameter containers are stock torch modules created in the reference's order, so a seeded construction
+    reproduces the reference's random init bit-for-bit (fixture 'model_skip' was built with seed 401)."""
+    ref = sub(load_golden("model_skip"), "p/")
+    torch.manual_seed(401)
+    m = U.TemporalUNetDualView(1, 1, base_ch=4, lstm_layers=1, use_skip_lstm=True, use_attention=False)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
+def test_no_cpu_fallback():
+    m = U.TemporalUNetDualView(base_ch=4)
+    with pytest.raises(U.UclstmError):
+        m(torch.rand(1, 2, 2, 16, 16))
+    with pytest.raises(U.UclstmError):
+        U.ConvLSTMCell(2, 4)(torch.rand(1, 2, 8, 8))
+    with pytest.raises(U.UclstmError):
+        U.compute_loss(torch.rand(1, 2, 1, 8, 8), torch.rand(1, 2, 1, 8, 8))
+    with pytest.raises(RuntimeError):
+        U.FusedAdamW([torch.nn.Parameter(torch.zeros(3))])
+
+
+def test_npz_dataset_matches_reference_fixture(tmp_path):
+    g = load_golden("dataset")
+    path = tmp_path / "ds.npz"
+    np.savez(path, X=g["X"].numpy(), Y=g["Y"].numpy())
+    ds = U.NPZSequenceDataset(str(path))
+    for k in ("norm_const", "min_vel", "max_vel", "y_scale", "trans_min", "trans_max"):
+        assert abs(getattr(ds, k) - float(g[k])) <= 1e-6 * max(1.0, abs(float(g[k]))), k
+    x, y, m = ds[1]
+    torch.testing.assert_close(x, g["x1"])
+    torch.testing.assert_close(y, g["y1"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(m, g["mask1"])
+    torch.testing.assert_close(ds.denormalize(y).double(), g["denorm_y1"].double(), rtol=1e-5, atol=1e-5)
+    assert len(ds) == 3
+
+
+def test_synthetic_sequences_shapes_and_determinism():
+    a = U.SyntheticSequences(2, 5, 32, 32, seed=3, kind="blobs", device="cpu")
+    b = U.SyntheticSequences(2, 5, 32, 32, seed=3, kind="blobs", device="cpu")
+    assert a.x.shape == (2, 5, 2, 32, 32) and a.y.shape == (2, 5, 1, 32, 32) and a.mask.shape == a.y.shape
+    assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y)
+    assert torch.equal(a.x[:, :, 0], a.x[:, :, 1])                       # frame duplicated into both views
+    assert float(a.y.abs().max()) <= 1.0 and float(a.x.max()) <= 1.0
+    u = U.SyntheticSequences(2, 3, 16, 16, seed=1, kind="uniform", device="cpu")
+    assert 0.0 <= float(u.x.min()) and float(u.x.max()) < 1.0 and -1.0 <= float(u.y.min()) and float(u.y.max()) < 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# flat parameters + data-parallel gradient exchange (gloo, world_size 2)
+# ---------------------------------------------------------------------------------------------
+def test_flat_params_views_and_zero_grad():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    before = [p.detach().clone() for p in net.parameters()]
+    fp = FlatParams(net.parameters())
+    assert fp.numel == sum(p.numel() for p in net.parameters())
+    for p, b, o in zip(net.parameters(), before, fp.offsets):
+        assert torch.equal(p, b) and p.data_ptr() == fp.flat_p.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == fp.flat_g.data_ptr() + 4 * o
+    net(torch.randn(4, 5)).sum().backward()
+    assert float(fp.flat_g.abs().sum()) > 0
+    for p, o in zip(net.parameters(), fp.offsets):                       # autograd accumulated IN PLACE into the flat buffer
+        assert p.grad.data_ptr() == fp.flat_g.data_ptr() + 4 * o
+    fp.zero_grad()
+    assert float(fp.flat_g.abs().sum()) == 0
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                          # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    net.register_buffer("stat", torch.full((3,), float(rank)))
+    fp = FlatParams(net.parameters())
+    ddp = FlatDDP(net, fp, bucket_mb=30 * 4 / (1 << 20))   # >= 30 floats per bucket -> three buckets
+    p0 = fp.flat_p.clone()
+    launched_during_backward = []
+    orig = ddp._launch
+
+    def spy(bi):
+        launched_during_backward.append(bi)
+        orig(bi)
+    ddp._launch = spy
+    torch.manual_seed(7 + rank)
+    x = torch.randn(8, 6)
+    fp.zero_grad()
+    ddp.reset()
+    net(x).pow(2).mean().backward()
+    n_early = len(launched_during_backward)
+    ddp.finalize()
+    # numpy copies: pickled by value (torch tensors would travel as shared-memory handles that die with this process)
+    q.put((rank, p0.numpy().copy(), fp.flat_g.numpy().copy(), x.numpy().copy(), n_early, len(ddp.buckets), net.stat.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [tuple(torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in r) for r in res]
+    (_, p_a, g_a, x_a, early_a, nb, stat_a), (_, p_b, g_b, x_b, early_b, _, stat_b) = res
+    assert torch.equal(p_a, p_b)                           # parameters broadcast from rank 0
+    assert torch.equal(stat_a, stat_b) and float(stat_a[0]) == 0.0      # buffers too
+    assert torch.equal(g_a, g_b)                           # every rank holds the same averaged gradient
+    assert nb >= 3 and early_a == nb and early_b == nb     # every bucket was launched from a backward hook (overlap)
+    # reference: mean of the two ranks' local gradients
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    fp = FlatParams(net.parameters())
+    fp.flat_p.copy_(p_a)
+    gs = []
+    for x in (x_a, x_b):
+        fp.zero_grad()
+        net(x).pow(2).mean().backward()
+        gs.append(fp.flat_g.clone())
+    torch.testing.assert_close(g_a, (gs[0] + gs[1]) / 2, rtol=1e-6, atol=1e-7)

@@ -39,7 +39,42 @@ int ew_grid(int64_t items) {
 // ---------------------------------------------------------------------------------------------
 // BatchNorm finalize
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C, double inv_cnt,
+// Pass 1: one block per (group, 64-channel slab), 16 tile lanes x 64 channels: sum the conv epilogue's per-tile partials in
+// f64 and leave (mean, biased variance) in the group's tile-0 slot of the SAME buffer (each (group, channel) column is read
+// only by its own block, and written after the block's barrier).
+__global__ __launch_bounds__(1024) void bn_reduce_kernel(float* __restrict__ stats, int tpg, int Cp, double inv_cnt) {
+    __shared__ double r1[16][64], r2[16][64];
+    const int g = blockIdx.x;
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < Cp) {
+        for (int t = lane; t < tpg; t += 16) {
+            const float2 v = *(const float2*)(stats + (((long)g * tpg + t) * Cp + c) * 2);
+            s1 += v.x;
+            s2 += v.y;
+        }
+    }
+    r1[lane][cl] = s1;
+    r2[lane][cl] = s2;
+    __syncthreads();
+    if (lane == 0 && c < Cp) {
+        s1 = 0.0;
+        s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s1 += r1[k][cl];
+            s2 += r2[k][cl];
+        }
+        const double m = s1 * inv_cnt;
+        double var = s2 * inv_cnt - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        *(float2*)(stats + ((long)g * tpg * Cp + c) * 2) = make_float2((float)m, (float)var);
+    }
+}
+
+// Pass 2: per channel, groups IN ORDER (running statistics are a sequential momentum recursion).
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C,
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
@@ -53,16 +88,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
         float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
         if (real) {
             if (stats) {
-                double s1 = 0.0, s2 = 0.0;
-                for (int t = 0; t < tpg; ++t) {
-                    const float* sp = stats + (((long)g * tpg + t) * Cp + c) * 2;
-                    s1 += sp[0];
-                    s2 += sp[1];
-                }
-                const double m = s1 * inv_cnt;
-                double var = s2 * inv_cnt - m * m;
-                var = var < 0.0 ? 0.0 : var;
-                mu = (float)m;
+                const float2 mv = *(const float2*)(stats + ((long)g * tpg * Cp + c) * 2);
+                const double var = (double)mv.y;
+                mu = mv.x;
                 rs = (float)(1.0 / sqrt(var + (double)eps));
                 // running stats: one momentum step per group, in group order (train/unet.py:179,:196)
                 rm = (1.f - momentum) * rm + momentum * mu;
@@ -540,17 +568,21 @@ bool aligned16(const void* p) { return p && ((uintptr_t)p % 16) == 0; }
 }  // namespace
 
 // =============================================================================================
-extern "C" int32_t uclstm_bn_finalize(const float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
+extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                                       int64_t count_per_group, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                                       float* rstd, void* stream) {
     if (groups <= 0 || Cp <= 0 || C <= 0 || C > Cp || !gamma || !beta || !running_mean || !running_var || !scale || !shift)
         return UCLSTM_E_BADARG;
     if (stats && (tiles_per_group <= 0 || count_per_group <= 0)) return UCLSTM_E_BADARG;
-    const double inv = stats ? 1.0 / (double)count_per_group : 0.0;
     const double unb = (stats && count_per_group > 1) ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
+    if (stats) {
+        // the partial-sum buffer is consumed (tile-0 slots are overwritten with mean/variance)
+        UCLSTM_LAUNCH(bn_reduce_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, const_cast<float*>(stats),
+                      tiles_per_group, Cp, 1.0 / (double)count_per_group);
+    }
     UCLSTM_LAUNCH(bn_finalize_kernel, dim3((Cp + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C,
-                       inv, unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+                  unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     return UCLSTM_OK;
 }
 
