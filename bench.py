@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-skip-lstm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", action="store_true", help="per-shape table of the instrumented step (stderr)")
     return ap.parse_args()
 
 
@@ -140,13 +141,24 @@ def main():
         step()
         torch.cuda.synchronize()
         agg = {}
-        for kind, flops, e0, e1 in ops.PROFILE:
+        rows = []
+        for kind, flops, e0, e1, note in ops.PROFILE:
             t_ms = e0.elapsed_time(e1)
+            rows.append((t_ms, kind, flops, note))
             k = agg.setdefault(kind, [0.0, 0.0, 0])
             k[0] += flops
             k[1] += t_ms
             k[2] += 1
         ops.PROFILE = None
+        if a.dump_launches:
+            merged = {}
+            for t_ms, kind, flops, note in rows:
+                m = merged.setdefault((kind, note), [0.0, 0.0, 0])
+                m[0] += t_ms
+                m[1] += flops
+                m[2] += 1
+            for (kind, note), (t_ms, flops, n) in sorted(merged.items(), key=lambda kv: -kv[1][0]):
+                log(f"{kind:16s} x{n:3d} {t_ms:8.3f} ms {flops / t_ms / 1e9:7.1f} TF/s  {note}")
         if agg:
             dom = max(agg, key=lambda k: agg[k][1])
             fl, ms, n = agg[dom]

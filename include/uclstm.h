@@ -62,6 +62,8 @@ typedef struct {
 
 #define UCLSTM_EPI_STORE 0   /* bias (+ per-column affine, ReLU) -> bf16 segments (+ BN partial sums) */
 #define UCLSTM_EPI_LSTM  1   /* gate nonlinearities + cell update, train/unet.py:29-35                */
+#define UCLSTM_EPI_ATOMIC 2  /* split-K: f32 atomic accumulation of the raw tile into acc_out (small-M GEMMs
+                              * of the ConvLSTM recurrence, where 128x128 tiles alone cannot fill 256 CUs)    */
 
 typedef struct {
     /* output pixel grid: n_img images of H x W; BatchNorm statistic groups (timesteps)
@@ -91,6 +93,10 @@ typedef struct {
     float* c_out;                /* f32 [pixels][Hd_p] */
     void* h_out;                 /* bf16 [pixels][Hd_p] */
     void* gates_out;             /* bf16 [pixels][4][Hd_p] post-activation i,f,g,o or NULL (inference) */
+    /* UCLSTM_EPI_ATOMIC: acc_out[pixel*acc_ld + n] += tile (no bias); the caller zeroes / pre-loads acc_out */
+    float* acc_out;
+    int32_t acc_ld;
+    int32_t ksplit;              /* requested K ranges (>= 1) */
 } uclstm_igemm_desc;
 
 /* Rows of `stats` per group for a descriptor: ceil((n_img/groups)*H*W / 128). */
@@ -189,8 +195,12 @@ int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_i
 /* dh = dh_a (+ dh_b); dc = dc_io + dh*o*(1-tanh(c)^2); dgates = pre-activation gradients
  * bf16 [pixels][4][Hd_p] (i,f,g,o); dc_io <- dc*f (gradient w.r.t. c_prev). */
 int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new,
-                                  const void* dh_a, const void* dh_b, float* dc_io, int32_t dc_is_zero,
+                                  const void* dh_a, const void* dh_b, int32_t dh_b_is_f32, float* dc_io, int32_t dc_is_zero,
                                   void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
+/* Gate nonlinearities + cell update (train/unet.py:29-35) for the split-K form of the cell: `pre` is the f32
+ * pre-activation [pixels][N] in the gate-interleaved panel-row order (N = 64*ceil(Hd/16)), bias in the same order. */
+int32_t uclstm_lstm_fwd_pointwise(const float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
+                                  void* gates_out, int64_t pixels, int32_t Hd_p, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Layout / boundary kernels                                                            */

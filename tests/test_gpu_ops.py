@@ -310,6 +310,42 @@ def test_convlstm_cell_golden(tag):
     check_f32(cn.cpu(), f["c1_none"], "cell c1 (state=None)", l2=1e-2)
 
 
+def test_lstm_fused_kernel_and_split_k_form_agree():
+    """The fused cell kernel (gates in registers) and its split-K form (f32 atomic partial tiles + point-wise cell
+    update, used when B*h*w is too small to fill the chip) compute the same step."""
+    torch.manual_seed(9)
+    B, H, W, Cx, Hd = 3, 9, 10, 24, 40
+    x, h = to_nhwc(torch.randn(B, Cx, H, W)), to_nhwc(torch.randn(B, Hd, H, W) * 0.5)
+    c = torch.zeros(B, H, W, cpad(Hd), device=DEV)
+    c[..., :Hd] = torch.randn(B, H, W, Hd, device=DEV) * 0.5
+    wt = (torch.randn(4 * Hd, Cx + Hd, 3, 3) * 0.05).to(DEV)
+    bs = (torch.randn(4 * Hd) * 0.1).to(DEV)
+    pd = ops.lstm_pack_desc(Hd, Cx)
+    wp, bp = ops.pack_weights(pd, wt), ops.pack_bias(pd, bs)
+    Hdp = cpad(Hd)
+
+    def outs():
+        return (torch.zeros(B, H, W, Hdp, device=DEV), torch.zeros(B, H, W, Hdp, dtype=torch.bfloat16, device=DEV),
+                torch.zeros(B, H, W, 4, Hdp, dtype=torch.bfloat16, device=DEV))
+    c1, h1, g1 = outs()
+    ops.igemm_lstm(x, h, wp, bp, c, c1, h1, g1)
+    c2, h2, g2 = outs()
+    pre = torch.zeros(B * H * W, wp.shape[0], device=DEV)
+    ops.igemm_atomic([ops.SrcView(x), ops.SrcView(h)], wp, (H, W), B, pre, 5, ktap=3, pad=1)
+    L = U._lib
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(pre.data_ptr(), bp.data_ptr(), c.data_ptr(), c2.data_ptr(), h2.data_ptr(), g2.data_ptr(),
+                                            B * H * W, Hdp, None), "lstm_fwd_pointwise")
+    check_f32(c2.cpu(), c1.cpu(), "split-K cell c vs fused", l2=1e-5)
+    check_bf16(h2.float().cpu(), h1.float().cpu(), "split-K cell h vs fused", l2=1e-3, mx=8e-3)
+    check_bf16(g2.float().cpu(), g1.float().cpu(), "split-K cell gates vs fused", l2=1e-3, mx=8e-3)
+    # and against the oracle on the same rounded operands
+    xr, hr = from_nhwc(x, Cx), from_nhwc(h, Hd)
+    cr = c[..., :Hd].cpu().permute(0, 3, 1, 2)
+    h_ref, c_ref = O.convlstm_cell(xr, hr, cr, bf(wt.cpu()), bs.cpu())
+    check_bf16(from_nhwc(h1, Hd), h_ref, "fused cell h vs oracle")
+    check_f32(c1[..., :Hd].cpu().permute(0, 3, 1, 2), c_ref, "fused cell c vs oracle", l2=1e-4)
+
+
 def test_convlstm_two_layer_sequence_golden():
     g = load_golden("seq")
     lstm = U.ConvLSTM(4, 8, num_layers=2).to(DEV)

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
 ABI_VERSION = 1
-EPI_STORE, EPI_LSTM = 0, 1
+EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
 
@@ -51,7 +51,8 @@ class IgemmDesc(C.Structure):
                 ("nseg", C.c_int32), ("seg", Seg * 4),
                 ("stats", C.c_void_p),
                 ("Hd_p", C.c_int32), ("c_prev", C.c_void_p), ("c_out", C.c_void_p), ("h_out", C.c_void_p),
-                ("gates_out", C.c_void_p)]
+                ("gates_out", C.c_void_p),
+                ("acc_out", C.c_void_p), ("acc_ld", C.c_int32), ("ksplit", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -89,7 +90,8 @@ _PROTOS = {
     "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "uclstm_maxpool2_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P],
+    "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P],
+    "uclstm_lstm_fwd_pointwise": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
     "uclstm_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],
     "uclstm_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
     "uclstm_nchw_grad_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],

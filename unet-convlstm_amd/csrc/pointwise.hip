@@ -292,9 +292,51 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // ---------------------------------------------------------------------------------------------
 // ConvLSTM backward, point-wise part
 // ---------------------------------------------------------------------------------------------
+// Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
+// (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
+__global__ void lstm_fwd_pw_kernel(const float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ c_prev,
+                                   float* __restrict__ c_out, bf16* __restrict__ h_out, bf16* __restrict__ gates_out, int64_t items,
+                                   FastDiv dq, int Hd_p, int N) {
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dq);
+        const int hc = ((uint32_t)idx - pix * dq.d) * 4;                 // first hidden channel of the quad
+        const int nb = (hc >> 4) * 64 + (hc & 15);
+        const float* pp = pre + (int64_t)pix * N + nb;
+        float g4[4][4];
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const float4 v = *(const float4*)(pp + gate * 16);
+            const float4 b = bias ? *(const float4*)(bias + nb + gate * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g4[gate][0] = v.x + b.x; g4[gate][1] = v.y + b.y; g4[gate][2] = v.z + b.z; g4[gate][3] = v.w + b.w;
+        }
+        float cp[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t so = (int64_t)pix * Hd_p + hc;
+        if (c_prev) { const float4 t = *(const float4*)(c_prev + so); cp[0] = t.x; cp[1] = t.y; cp[2] = t.z; cp[3] = t.w; }
+        float cn[4];
+        Pack8 hi, gi, gf, gg, go;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vi = fast_sigmoid(g4[0][r]), vf = fast_sigmoid(g4[1][r]);
+            const float vg = fast_tanh(g4[2][r]), vo = fast_sigmoid(g4[3][r]);
+            cn[r] = vf * cp[r] + vi * vg;
+            hi.e[r] = f32_to_bf16(vo * fast_tanh(cn[r]));
+            gi.e[r] = f32_to_bf16(vi); gf.e[r] = f32_to_bf16(vf); gg.e[r] = f32_to_bf16(vg); go.e[r] = f32_to_bf16(vo);
+        }
+        *(float4*)(c_out + so) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+        *(uint2*)(h_out + so) = hi.u;
+        if (gates_out) {
+            bf16* gp = gates_out + (int64_t)pix * 4 * Hd_p + hc;
+            *(uint2*)(gp) = gi.u;
+            *(uint2*)(gp + Hd_p) = gf.u;
+            *(uint2*)(gp + 2 * Hd_p) = gg.u;
+            *(uint2*)(gp + 3 * Hd_p) = go.u;
+        }
+    }
+}
+
 __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
-                                   const uint4* __restrict__ dh_a, const uint4* __restrict__ dh_b, float* __restrict__ dc_io,
-                                   int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
+                                   const uint4* __restrict__ dh_a, const void* __restrict__ dh_b, int dh_b_is_f32,
+                                   float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
     const int cpc = dcpc.d;
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
         const uint32_t pix = fdiv((uint32_t)idx, dcpc);
@@ -316,7 +358,8 @@ __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float*
         if (dh_a) unpack8(dh_a[idx], dh);
         if (dh_b) {
             float t[8];
-            unpack8(dh_b[idx], t);
+            if (dh_b_is_f32) load8f((const float*)dh_b + idx * 8, t);
+            else unpack8(((const uint4*)dh_b)[idx], t);
 #pragma unroll
             for (int i = 0; i < 8; ++i) dh[i] += t[i];
         }
@@ -651,16 +694,28 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, 
     return UCLSTM_OK;
 }
 
+extern "C" int32_t uclstm_lstm_fwd_pointwise(const float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
+                                             void* gates_out, int64_t pixels, int32_t Hd_p, void* stream) {
+    if (!aligned16(pre) || !aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
+    if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return UCLSTM_E_BADARG;
+    const int64_t items = pixels * (Hd_p / 4);
+    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    const int N = 64 * ((Hd_p + 15) / 16);
+    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, bias, c_prev, c_out, (bf16*)h_out,
+                  (bf16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
+    return UCLSTM_OK;
+}
+
 extern "C" int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new, const void* dh_a,
-                                             const void* dh_b, float* dc_io, int32_t dc_is_zero, void* dgates, int64_t pixels,
-                                             int32_t Hd_p, void* stream) {
+                                             const void* dh_b, int32_t dh_b_is_f32, float* dc_io, int32_t dc_is_zero, void* dgates,
+                                             int64_t pixels, int32_t Hd_p, void* stream) {
     if (!aligned16(gates) || !aligned16(c_new) || !aligned16(dc_io) || !aligned16(dgates) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8))
         return UCLSTM_E_BADARG;
     if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Hd_p / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
-                       (const uint4*)dh_a, (const uint4*)dh_b, dc_io, dc_is_zero, (uint4*)dgates, chunks, make_fastdiv(Hd_p / 8));
+                       (const uint4*)dh_a, dh_b, dh_b_is_f32, dc_io, dc_is_zero, (uint4*)dgates, chunks, make_fastdiv(Hd_p / 8));
     return UCLSTM_OK;
 }
 

@@ -50,7 +50,7 @@ def _p(t: Optional[torch.Tensor]):
 PROFILE: Optional[list] = None
 
 
-def _timed(kind: str, flops: float, launch) -> None:
+def _timed(kind: str, flops: float, launch, note: str = "") -> None:
     if PROFILE is None:
         launch()
         return
@@ -59,7 +59,7 @@ def _timed(kind: str, flops: float, launch) -> None:
     e0.record()
     launch()
     e1.record()
-    PROFILE.append((kind, flops, e0, e1))
+    PROFILE.append((kind, flops, e0, e1, note))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -247,7 +247,34 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
         _fill_seg(d.seg[i], *sg)
     d.stats = None if stats is None else stats.data_ptr()
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
-    _timed("igemm_fwd_store", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"))
+    _timed("igemm_fwd_store", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
+           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}")
+
+
+def split_k_factor(pixels: int, N: int, ksteps: int, min_blocks: int = 384, target: int = 512) -> int:
+    """K ranges for a GEMM whose 128x128 tile grid alone cannot fill the 256 CUs (the per-timestep GEMMs of the
+    ConvLSTM recurrence: M = B*h*w is as small as 512).  1 = do not split."""
+    tiles = ((pixels + 127) // 128) * ((N + 127) // 128)
+    if tiles >= min_blocks:
+        return 1
+    return max(1, min((target + tiles - 1) // tiles, ksteps // 8))
+
+
+def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
+                 ktap: int, scale: int = 1, pad: int = 0) -> None:
+    """acc_out[pixel, n] += conv(srcs)[pixel, n] as `ksplit` K ranges with f32 atomics (acc_out f32 [pixels, ld>=N])."""
+    _dev(acc_out, F32, "acc_out")
+    d = L.IgemmDesc()
+    d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], 1
+    d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
+    for i, s in enumerate(srcs):
+        s.fill(d.src[i])
+    d.wp, d.N, d.Ktot = wp.data_ptr(), wp.shape[0], wp.shape[1]
+    d.relu, d.epi, d.nseg = 0, L.EPI_ATOMIC, 0
+    d.acc_out, d.acc_ld, d.ksplit = acc_out.data_ptr(), acc_out.shape[-1], ksplit
+    flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
+    _timed("igemm_fwd_atomic", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
+           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
 
 
 def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
@@ -266,7 +293,8 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
     d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
     flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * (x.shape[3] + h_prev.shape[3])
-    _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"))
+    _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
+           f"M={B * H * W} N={d.N} K={d.Ktot}")
 
 
 def wgrad_splits(n_tiles: int, pixels: int) -> int:
@@ -294,7 +322,8 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     d.splits = wgrad_splits(n_tiles, n_img * out_hw[0] * out_hw[1])
     d.accumulate = 1
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
-    _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"))
+    _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
+           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
     return dwp
 
 
@@ -644,9 +673,21 @@ class ConvLSTMSeq(torch.autograd.Function):
         if c0 is not None:
             c_hist[0].copy_(c0)
         gates = torch.empty((T, B, H, W, 4, Hdp), dtype=BF16, device=dev) if need_grad else None
+        # Per-step GEMM M = B*H*W.  When its 128x128 tile grid cannot fill the chip (bottleneck LSTM: M = 512), run the
+        # gate convolution as split-K partial tiles accumulated in f32 and apply the cell update in a point-wise kernel;
+        # otherwise one fused kernel per step (gates never leave registers).
+        ksplit = split_k_factor(B * H * W, wp.shape[0], wp.shape[1] // 64)
+        pre = torch.empty((B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
-            igemm_lstm(x_all[t], h_hist[t], wp, bp, c_hist[t] if (c0 is not None or t > 0) else None, c_hist[t + 1], h_hist[t + 1],
-                       gates[t] if need_grad else None, ks)
+            c_prev = c_hist[t] if (c0 is not None or t > 0) else None
+            g_t = gates[t] if need_grad else None
+            if ksplit > 1:
+                pre.zero_()
+                igemm_atomic([SrcView(x_all[t]), SrcView(h_hist[t])], wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2)
+                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), _p(bp), _p(c_prev), _p(c_hist[t + 1]), _p(h_hist[t + 1]), _p(g_t),
+                                                        B * H * W, Hdp, _stream()), "lstm_fwd_pointwise")
+            else:
+                igemm_lstm(x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks)
         if need_grad:
             ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates)
             ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
@@ -669,17 +710,25 @@ class ConvLSTMSeq(torch.autograd.Function):
         ddh = lstm_dgrad_pack_desc(Hd, Cx, Hd, ks)
         wd_h = pack_weights(ddh, weight, Cx * ks * ks)
         dh_rec = None
-        buf = [torch.empty((B, H, W, Hdp), dtype=BF16, device=dev) for _ in range(2)]
+        # recurrent gradient dh_{t-1} = W_h^T (*) dgates_t: M = B*H*W pixels, N = Hd, K = 9*4*Hd.  Small M -> split-K with
+        # f32 atomics into dh (read back as f32 by the next step's point-wise kernel); else a plain bf16 store.
+        ksplit = split_k_factor(pixels, ddh.N, ddh.Ktot // 64)
+        rec_dtype = F32 if ksplit > 1 else BF16
+        buf = [torch.empty((B, H, W, Hdp), dtype=rec_dtype, device=dev) for _ in range(2)]
         need_h0 = ctx.needs_input_grad[1]
         for t in range(T - 1, -1, -1):
             c_prev = c_hist[t] if (has_c0 or t > 0) else None
             L.check(L.lib.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
-                                                    _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec), _p(dc),
+                                                    _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec), int(ksplit > 1), _p(dc),
                                                     int(dc_zero), _p(dgates[t]), pixels, Hdp, _stream()), "lstm_bwd_pointwise")
             dc_zero = False
             if t > 0 or need_h0:
                 dh_rec = buf[t & 1]
-                igemm_store([SrcView(dgates[t])], wd_h, (H, W), B, [(dh_rec, 0, ddh.N, 0, 1, 0, 0)], ktap=ks, pad=ks // 2)
+                if ksplit > 1:
+                    dh_rec.zero_()
+                    igemm_atomic([SrcView(dgates[t])], wd_h, (H, W), B, dh_rec.view(pixels, Hdp), ksplit, ktap=ks, pad=ks // 2)
+                else:
+                    igemm_store([SrcView(dgates[t])], wd_h, (H, W), B, [(dh_rec, 0, ddh.N, 0, 1, 0, 0)], ktap=ks, pad=ks // 2)
         dg_flat = dgates.view(T * B, H, W, 4 * Hdp)
         x_flat = x_all.reshape(T * B, H, W, Cxp)
         hprev_flat = h_hist[:T].reshape(T * B, H, W, Hdp)
@@ -698,7 +747,7 @@ class ConvLSTMSeq(torch.autograd.Function):
             dx_all = torch.empty_like(x_all)
             igemm_store([SrcView(dg_flat)], wd_x, (H, W), T * B, [(dx_all.view(T * B, H, W, Cxp), 0, ddx.N, 0, 1, 0, 0)], ktap=ks,
                         pad=ks // 2)
-        dh0 = dh_rec if need_h0 else None
+        dh0 = (dh_rec if dh_rec.dtype == BF16 else dh_rec.to(BF16)) if need_h0 else None
         dc0 = dc if (has_c0 and ctx.needs_input_grad[2]) else None
         return dx_all, dh0, dc0, dweight, dbias, None, None, None
 
