@@ -51,7 +51,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", default="", help="restrict to one named shape (e.g. down2.3, temporal)")
     a = ap.parse_args()
+    global CONVS, LSTMS
+    if a.shape:
+        CONVS = [c for c in CONVS if c[0] == a.shape]
+        LSTMS = [l for l in LSTMS if l[0] == a.shape]
     tot_ms = tot_fl = 0.0
     if a.only in ("", "fwd"):
         for name, H, C0, C1, Co in CONVS:

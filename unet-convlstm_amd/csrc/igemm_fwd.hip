@@ -10,9 +10,10 @@
 // owns 4 consecutive output channels of one pixel, which makes the LSTM gate quadruple
 // (i,f,g,o of one hidden channel = 4 M-subtiles of a wave) lane-local and lets the epilogue
 // pack 8-byte channel runs.  LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte
-// chunk (conflict-free ds_read_b128, guide T2).  Global->register->LDS staging is split
-// (issue loads for step s+1 before the MFMAs of step s, write LDS after; guide T14), one
-// barrier per K-step, two LDS stages.
+// chunk (conflict-free ds_read_b128, guide T2).  Operands go global->LDS directly
+// (global_load_lds, 16 B/lane): per staged row the tap-(0,0) offset and a 9-bit "tap inside the
+// image" mask are computed once, so a K-step costs ~1 VALU per MFMA instead of ~4.4 (measured:
+// the register-staged version was VALU-issue bound).  Two LDS stages, one barrier per K-step.
 #include "common.h"
 
 namespace {
@@ -25,6 +26,9 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // X tile then W tile
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB
 constexpr int OT_PITCH = BN * 2 + 16;            // staged output tile: bytes per pixel row
 
+// 16-byte zero page: the source of every padded / out-of-tile operand row of the direct-to-LDS loads
+__device__ uint4 g_zero_page[2];
+
 struct Derived {
     int Mg;          // pixels per statistic group
     int tpg;         // M tiles per group
@@ -34,6 +38,7 @@ struct Derived {
     int ksteps;      // total K steps
     int ksplit;      // K ranges (UCLSTM_EPI_ATOMIC only, else 1)
     int kper;        // K steps per range
+    FastDiv dHW, dW; // pixel index -> (image, y, x)
 };
 
 template <int EPI>
@@ -64,28 +69,57 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     const int n0 = nt * BN;
     const int HW = d.H * d.W;
 
-    // ---- rows this thread stages: lrow0 + 32*i, 16-byte chunk lchunk ----
-    const int lchunk = tid & 7;
-    const int lrow0 = tid >> 3;
-    int pn[4], py[4], px[4];
+    // ---- operand staging: direct-to-LDS loads (global_load_lds, 16 B per lane, guide section 5) ----
+    // DMA instruction i of wave w fills LDS rows 32*i + 8*w + (lane>>3), 16-byte position lane&7, of the X and the W tile
+    // (1 KiB contiguous per wave instruction).  The XOR swizzle sits on the SOURCE side: position p of row r receives
+    // channel chunk p ^ (r&7) (rule 21: linear destination, swizzled source, swizzled read).  Rows whose tap falls
+    // outside the image, or beyond the tile's last pixel, read a 16-byte zero page instead.
+    const int lrow0 = tid >> 3;                        // = 8*wave + (lane>>3)
+    const int lchunk = (tid & 7) ^ (lrow0 & 7);        // channel chunk that belongs at this lane's LDS position
+    const uint64_t zero_addr = (uint64_t)(const void*)g_zero_page;
+
+    // per staged row: element offset of tap (0,0) in each source, and a bit mask of the taps that land inside the image
+    int roff0[4], roff1[4];
+    uint32_t vm0[4], vm1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = lrow0 + 32 * i;
-        if (r < rows_valid) {
-            const long m = m0 + r;
-            const int img = (int)(m / HW);
-            const int rem = (int)(m - (long)img * HW);
-            const int y = rem / d.W;
-            pn[i] = img;
-            py[i] = y;
-            px[i] = rem - y * d.W;
-        } else {
-            pn[i] = 0;
-            py[i] = -(1 << 20);   // every tap lands outside the image -> zero fill
-            px[i] = 0;
+        const bool rvalid = r < rows_valid;
+        const uint32_t m = (uint32_t)(m0 + (rvalid ? r : 0));
+        const int img = (int)fdiv(m, dv.dHW);
+        const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+        const int y = (int)fdiv(rem, dv.dW);
+        const int x = (int)rem - y * d.W;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            int ro = 0;
+            uint32_t mk = 0;
+            if (sidx < d.nsrc) {
+                const uclstm_src S = d.src[sidx];
+                const int ys0 = y * d.scale - d.pad - S.offY;
+                const int xs0 = x * d.scale - d.pad - S.offX;
+                ro = ((img * S.Hs + ys0) * S.Ws + xs0) * S.C + lchunk * 8;
+                if (rvalid) {
+                    // tap (j,k) is inside the image iff row j and column k are: 3 + 3 compares, no division
+                    uint32_t colm = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1u << k;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < d.ktap && (unsigned)(ys0 + j) < (unsigned)S.Hs) mk |= colm << (j * d.ktap);
+                }
+            }
+            if (sidx == 0) { roff0[i] = ro; vm0[i] = mk; } else { roff1[i] = ro; vm1[i] = mk; }
         }
     }
-    const int sw = (lchunk ^ (lrow0 & 7)) << 4;   // swizzled chunk byte offset (row & 7 is i-invariant)
+    // weight panel rows (clamped: rows >= N feed accumulators that are never stored)
+    uint64_t wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nrow = min(n0 + lrow0 + 32 * i, d.N - 1);
+        wrow[i] = (uint64_t)d.wp + ((uint64_t)nrow * (uint64_t)d.Ktot + (uint64_t)(lchunk * 8)) * 2u;
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -104,30 +138,39 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         s = r >= s0steps ? 1 : 0;
         c0 = (s ? r - s0steps : r) * BK;
     }
-    uint4 ra[4], rb[4];
 
-    auto issue_loads = [&]() {
-        const uclstm_src S = d.src[s];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const int wrow_lds = wave * 8 * 128;               // this wave's first row in every 32-row group (bytes)
+
+    auto issue_src = [&](const int (&roff)[4], const uint32_t (&vmask)[4], const uclstm_src S, unsigned char* X) {
         const int tdy = tap / d.ktap;
-        const int dy = tdy - d.pad - S.offY;
-        const int dx = (tap - tdy * d.ktap) - d.pad - S.offX;
-        const int c = c0 + lchunk * 8;
-        const bool cvalid = c < S.C;
-        const bf16* base = (const bf16*)S.ptr;
+        const int tapoff = (tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0;      // wave-uniform
+        // lane-level validity as one AND (kept branch-free: a select per load, never a second exec-masked DMA)
+        const uint32_t tbit = (c0 + lchunk * 8 < S.C) ? (1u << tap) : 0u;
+        const uint64_t base = (uint64_t)S.ptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ys = py[i] * d.scale + dy;
-            const int xs = px[i] * d.scale + dx;
-            const bool ok = cvalid && (unsigned)ys < (unsigned)S.Hs && (unsigned)xs < (unsigned)S.Ws;
-            const bf16* p = base + (((long)pn[i] * S.Hs + ys) * S.Ws + xs) * (long)S.C + c;
-            ra[i] = ok ? *(const uint4*)p : make_uint4(0u, 0u, 0u, 0u);
+            const uint64_t a_in = base + (uint64_t)((long)(roff[i] + tapoff) * 2);
+            const uint32_t hit = vmask[i] & tbit;
+            uint32_t lo = (uint32_t)a_in, hi = (uint32_t)(a_in >> 32);
+            asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %1, %4, %1, vcc"
+                         : "+v"(lo), "+v"(hi)
+                         : "v"(hit), "v"((uint32_t)zero_addr), "v"((uint32_t)(zero_addr >> 32))
+                         : "vcc");
+            const uint64_t addr = ((uint64_t)hi << 32) | lo;
+            __builtin_amdgcn_global_load_lds((gbl_ptr)addr, (lds_ptr)(X + i * 32 * 128 + wrow_lds), 16, 0, 0);
         }
-        const bf16* wbase = (const bf16*)d.wp + (long)kstep * BK + lchunk * 8;
+    };
+    auto issue_loads = [&](int buf) {
+        unsigned char* X = smem + buf * STAGE_BYTES;
+        unsigned char* Wt = X + TILE_BYTES;
+        if (s == 0) issue_src(roff0, vm0, d.src[0], X);
+        else issue_src(roff1, vm1, d.src[1], X);
+        const uint64_t koff = (uint64_t)kstep * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nrow = n0 + lrow0 + 32 * i;
-            rb[i] = (nrow < d.N) ? *(const uint4*)(wbase + (long)nrow * d.Ktot) : make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow[i] + koff), (lds_ptr)(Wt + i * 32 * 128 + wrow_lds), 16, 0, 0);
         // advance cursor
         ++kstep;
         c0 += BK;
@@ -137,16 +180,6 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
                 s = 0;
                 ++tap;
             }
-        }
-    };
-    auto stage_store = [&](int buf) {
-        unsigned char* X = smem + buf * STAGE_BYTES;
-        unsigned char* Wt = X + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (lrow0 + 32 * i) * 128 + sw;
-            *(uint4*)(X + off) = ra[i];
-            *(uint4*)(Wt + off) = rb[i];
         }
     };
     auto compute = [&](int buf) {
@@ -168,16 +201,13 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
     };
 
-    // ---- main loop ----
+    // ---- main loop: DMA of step s+1 is in flight while step s computes; __syncthreads() drains it (vmcnt(0)) ----
     const int nsteps = kstep_end - kstep_begin;      // >= 1 by construction of ksplit
-    issue_loads();
-    stage_store(0);
+    issue_loads(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (more) issue_loads();
+        if (step + 1 < nsteps) issue_loads((step + 1) & 1);
         compute(step & 1);
-        if (more) stage_store((step + 1) & 1);
         __syncthreads();
     }
 
@@ -307,11 +337,11 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
             const int cc = q & 15;
             const int n = n0 + cc * 8;
             if (r >= rows_valid || n >= d.N) continue;
-            const long m = m0 + r;
-            const int img = (int)(m / HW);
-            const int rem = (int)(m - (long)img * HW);
-            const int y = rem / d.W;
-            const int x = rem - y * d.W;
+            const uint32_t m = (uint32_t)(m0 + r);
+            const int img = (int)fdiv(m, dv.dHW);
+            const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+            const int y = (int)fdiv(rem, dv.dW);
+            const int x = (int)rem - y * d.W;
 #pragma unroll
             for (int si = 0; si < 4; ++si) {
                 if (si < d.nseg && n >= d.seg[si].n_begin && n < d.seg[si].n_end) {
@@ -348,6 +378,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
     for (int s = 0; s < d.nsrc; ++s)
         if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;
+    for (int s = 0; s < d.nsrc; ++s)       // the kernel addresses operand rows with 32-bit element offsets
+        if ((int64_t)d.n_img * d.src[s].Hs * d.src[s].Ws * d.src[s].C >= ((int64_t)1 << 31) - (1 << 20)) return UCLSTM_E_BADARG;
     Derived dv;
     dv.kseg0 = round_up32(d.src[0].C, BK);
     dv.kseg1 = d.nsrc > 1 ? round_up32(d.src[1].C, BK) : 0;
@@ -355,7 +387,9 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (d.Ktot != taps * (dv.kseg0 + dv.kseg1)) return UCLSTM_E_BADARG;
     dv.ksteps = d.Ktot / BK;
     const int64_t mg = (int64_t)(d.n_img / d.groups) * d.H * d.W;
-    if (mg * d.groups > (int64_t)1 << 40) return UCLSTM_E_BADARG;
+    if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
+    dv.dW = make_fastdiv((uint32_t)d.W);
     dv.Mg = (int)mg;
     dv.tpg = (int)((mg + BM - 1) / BM);
     dv.n_mtiles = d.groups * dv.tpg;
