@@ -318,7 +318,7 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
         _fill_seg(d.seg[i], *sg)
     d.dwp = dwp.data_ptr()
     taps = ktap * ktap
-    n_tiles = ((N + 127) // 128) * taps * sum((s.t.shape[3] + 127) // 128 for s in srcs)
+    n_tiles = ((N + 127) // 128) * ((Ktot + 127) // 128)
     d.splits = wgrad_splits(n_tiles, n_img * out_hw[0] * out_hw[1])
     d.accumulate = 1
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
