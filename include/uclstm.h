@@ -99,8 +99,9 @@ typedef struct {
     int32_t ksplit;              /* requested K ranges (>= 1) */
 } uclstm_igemm_desc;
 
-/* Rows of `stats` per group for a descriptor: ceil((n_img/groups)*H*W / 128). */
-int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups);
+/* Rows of `stats` per group for a descriptor with N panel rows: ceil((n_img/groups)*H*W / tile_pixels),
+ * tile_pixels = 256 when N <= 64 (64 x 256 block shape) else 128. */
+int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups, int32_t N);
 
 /* out = conv(src) as one MFMA implicit GEMM.  Replaces, depending on the descriptor:
  *   nn.Conv2d 3x3 of DoubleConv (train/unet.py:70-71) incl. the cat([skip, up]) of :98,

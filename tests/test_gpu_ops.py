@@ -134,7 +134,7 @@ def test_conv3x3_padded_second_source_and_groups_stats():
     pd = ops.conv_pack_desc(16, 16, [8, 8], [8, 8])
     wp = ops.pack_weights(pd, w.to(DEV))
     out = torch.empty((N, H, W, 16), dtype=torch.bfloat16, device=DEV)
-    tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups)
+    tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups, 16)
     stats = torch.zeros((groups, tpg, 16, 2), device=DEV)
     ops.igemm_store([ops.SrcView(to_nhwc(x0)), ops.SrcView(to_nhwc(u), 0, 0)], wp, (H, W), N, [(out, 0, 16, 0, 1, 0, 0)],
                     ktap=3, pad=1, groups=groups, stats=stats)

@@ -65,7 +65,7 @@ def main():
             pd = ops.conv_pack_desc(Co, Ci, [C0] + ([C1] if C1 else []), [C0] + ([C1] if C1 else []))
             wp = ops.pack_weights(pd, torch.randn(Co, Ci, 3, 3, device=DEV) * 0.05)
             out = torch.empty(NIMG, H, H, Co, dtype=torch.bfloat16, device=DEV)
-            tpg = U._lib.lib.uclstm_igemm_tiles_per_group(NIMG, H, H, 20)
+            tpg = U._lib.lib.uclstm_igemm_tiles_per_group(NIMG, H, H, 20, Co)
             stats = torch.empty(20, tpg, Co, 2, device=DEV)
             ms = timeit(lambda: ops.igemm_store(srcs, wp, (H, H), NIMG, [(out, 0, Co, 0, 1, 0, 0)], ktap=3, pad=1, groups=20, stats=stats),
                         a.iters)

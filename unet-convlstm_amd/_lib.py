@@ -78,7 +78,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (restype int32 unless listed in _RESTYPES)
 _PROTOS = {
-    "uclstm_igemm_tiles_per_group": [_I, _I, _I, _I],
+    "uclstm_igemm_tiles_per_group": [_I, _I, _I, _I, _I],
     "uclstm_igemm_fwd": [C.POINTER(IgemmDesc), _P],
     "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
     "uclstm_pack_weights": [C.POINTER(PackDesc), _P, _P, _P],

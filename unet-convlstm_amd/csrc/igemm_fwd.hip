@@ -5,26 +5,22 @@
 // A is never materialised: for K-step (tap, source, 64-channel slice) row m of A is the 128
 // contiguous bytes src[s][img][y*scale+dy-pad][x*scale+dx-pad][c0:c0+64] (zeros outside the
 // image), so torch.cat([x,h]) / cat([skip,up]) / F.pad of the reference (train/unet.py:28,
-// :95-98) never exist in memory.  Tile 128 panel rows x 128 pixels x 64 K, 4 waves (2x2), each
-// wave 64x64 as 4x4 v_mfma_f32_16x16x32_bf16 with the PANEL as the MFMA A operand: a lane then
-// owns 4 consecutive output channels of one pixel, which makes the LSTM gate quadruple
-// (i,f,g,o of one hidden channel = 4 M-subtiles of a wave) lane-local and lets the epilogue
-// pack 8-byte channel runs.  LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte
-// chunk (conflict-free ds_read_b128, guide T2).  Operands go global->LDS directly
-// (global_load_lds, 16 B/lane): per staged row the tap-(0,0) offset and a 9-bit "tap inside the
-// image" mask are computed once, so a K-step costs ~1 VALU per MFMA instead of ~4.4 (measured:
-// the register-staged version was VALU-issue bound).  Two LDS stages, one barrier per K-step.
+// :95-98) never exist in memory.  4 waves per block, each wave a 64x64 output sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16 with the PANEL as the MFMA A operand: a lane then owns 4 consecutive
+// output channels of one pixel, which makes the LSTM gate quadruple (i,f,g,o of one hidden
+// channel = 4 M-subtiles of a wave) lane-local and lets the epilogue pack 8-byte channel runs.
+// Two block shapes: 128 panel rows x 128 pixels (waves 2x2) and, for C_out <= 64 layers,
+// 64 panel rows x 256 pixels (waves 1x4) so that no MFMA work is spent on absent channels.
+// LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte chunk (conflict-free
+// ds_read_b128, guide T2).  Operands go global->LDS directly (global_load_lds, 16 B/lane): per
+// staged row the tap-(0,0) offset and a 9-bit "tap inside the image" mask are computed once, so a
+// K-step costs ~1.5 VALU per MFMA instead of 4.4 (measured: the register-staged first version was
+// VALU-issue bound).  Two LDS stages, one barrier per K-step.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128;   // pixels per tile
-constexpr int BN = 128;   // panel rows per tile
 constexpr int BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // X tile then W tile
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB
-constexpr int OT_PITCH = BN * 2 + 16;            // staged output tile: bytes per pixel row
 
 // 16-byte zero page: the source of every padded / out-of-tile operand row of the direct-to-LDS loads
 __device__ uint4 g_zero_page[2];
@@ -41,15 +37,31 @@ struct Derived {
     FastDiv dHW, dW; // pixel index -> (image, y, x)
 };
 
-template <int EPI>
+template <int WN>
+struct Shape {
+    static constexpr int WM = 4 / WN;            // waves along pixels
+    static constexpr int TBN = 64 * WN;          // panel rows per tile
+    static constexpr int TBM = 64 * WM;          // pixels per tile
+    static constexpr int XR = TBM / 32;          // X rows staged per thread
+    static constexpr int WR = TBN / 32;          // W rows staged per thread
+    static constexpr int XBYTES = TBM * BK * 2;
+    static constexpr int WBYTES = TBN * BK * 2;
+    static constexpr int STAGE = XBYTES + WBYTES;
+    static constexpr int SMEM = 2 * STAGE;       // 64 KiB (128x128) / 80 KiB (64x256)
+    static constexpr int OT_PITCH = TBN * 2 + 16;
+};
+
+template <int EPI, int WN>
 __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+    using SH = Shape<WN>;
+    constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = wave >> 1;      // wave position along panel rows
-    const int wpx = wave & 1;      // wave position along pixels
+    const int wc = (WN == 2) ? (wave >> 1) : 0;      // wave position along panel rows
+    const int wpx = (WN == 2) ? (wave & 1) : wave;   // wave position along pixels
     const int l15 = lane & 15;
     const int lq = lane >> 4;
 
@@ -63,26 +75,26 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     const int kstep_end = min(dv.ksteps, kstep_begin + dv.kper);
     const int g = mt / dv.tpg;
     const int tile = mt - g * dv.tpg;
-    const int m_local0 = tile * BM;
+    const int m_local0 = tile * TBM;
     const long m0 = (long)g * dv.Mg + m_local0;
-    const int rows_valid = min(BM, dv.Mg - m_local0);
-    const int n0 = nt * BN;
+    const int rows_valid = min(TBM, dv.Mg - m_local0);
+    const int n0 = nt * TBN;
     const int HW = d.H * d.W;
 
     // ---- operand staging: direct-to-LDS loads (global_load_lds, 16 B per lane, guide section 5) ----
-    // DMA instruction i of wave w fills LDS rows 32*i + 8*w + (lane>>3), 16-byte position lane&7, of the X and the W tile
-    // (1 KiB contiguous per wave instruction).  The XOR swizzle sits on the SOURCE side: position p of row r receives
-    // channel chunk p ^ (r&7) (rule 21: linear destination, swizzled source, swizzled read).  Rows whose tap falls
-    // outside the image, or beyond the tile's last pixel, read a 16-byte zero page instead.
+    // DMA instruction i of wave w fills LDS rows 32*i + 8*w + (lane>>3), 16-byte position lane&7 (1 KiB contiguous per
+    // wave instruction).  The XOR swizzle sits on the SOURCE side: position p of row r receives channel chunk
+    // p ^ (r&7) (rule 21: linear destination, swizzled source, swizzled read).  Rows whose tap falls outside the image,
+    // or beyond the tile's last pixel, read a 16-byte zero page instead.
     const int lrow0 = tid >> 3;                        // = 8*wave + (lane>>3)
     const int lchunk = (tid & 7) ^ (lrow0 & 7);        // channel chunk that belongs at this lane's LDS position
     const uint64_t zero_addr = (uint64_t)(const void*)g_zero_page;
 
     // per staged row: element offset of tap (0,0) in each source, and a bit mask of the taps that land inside the image
-    int roff0[4], roff1[4];
-    uint32_t vm0[4], vm1[4];
+    int roff0[XR], roff1[XR];
+    uint32_t vm0[XR], vm1[XR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XR; ++i) {
         const int r = lrow0 + 32 * i;
         const bool rvalid = r < rows_valid;
         const uint32_t m = (uint32_t)(m0 + (rvalid ? r : 0));
@@ -114,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
     }
     // weight panel rows (clamped: rows >= N feed accumulators that are never stored)
-    uint64_t wrow[4];
+    uint64_t wrow[WR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WR; ++i) {
         const int nrow = min(n0 + lrow0 + 32 * i, d.N - 1);
         wrow[i] = (uint64_t)d.wp + ((uint64_t)nrow * (uint64_t)d.Ktot + (uint64_t)(lchunk * 8)) * 2u;
     }
@@ -143,14 +155,14 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
     const int wrow_lds = wave * 8 * 128;               // this wave's first row in every 32-row group (bytes)
 
-    auto issue_src = [&](const int (&roff)[4], const uint32_t (&vmask)[4], const uclstm_src S, unsigned char* X) {
+    auto issue_src = [&](const int (&roff)[XR], const uint32_t (&vmask)[XR], const uclstm_src S, unsigned char* X) {
         const int tdy = tap / d.ktap;
         const int tapoff = (tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0;      // wave-uniform
         // lane-level validity as one AND (kept branch-free: a select per load, never a second exec-masked DMA)
         const uint32_t tbit = (c0 + lchunk * 8 < S.C) ? (1u << tap) : 0u;
         const uint64_t base = (uint64_t)S.ptr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XR; ++i) {
             const uint64_t a_in = base + (uint64_t)((long)(roff[i] + tapoff) * 2);
             const uint32_t hit = vmask[i] & tbit;
             uint32_t lo = (uint32_t)a_in, hi = (uint32_t)(a_in >> 32);
@@ -163,13 +175,13 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
     };
     auto issue_loads = [&](int buf) {
-        unsigned char* X = smem + buf * STAGE_BYTES;
-        unsigned char* Wt = X + TILE_BYTES;
+        unsigned char* X = smem + buf * SH::STAGE;
+        unsigned char* Wt = X + SH::XBYTES;
         if (s == 0) issue_src(roff0, vm0, d.src[0], X);
         else issue_src(roff1, vm1, d.src[1], X);
         const uint64_t koff = (uint64_t)kstep * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WR; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow[i] + koff), (lds_ptr)(Wt + i * 32 * 128 + wrow_lds), 16, 0, 0);
         // advance cursor
         ++kstep;
@@ -183,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
     };
     auto compute = [&](int buf) {
-        const unsigned char* X = smem + buf * STAGE_BYTES;
-        const unsigned char* Wt = X + TILE_BYTES;
+        const unsigned char* X = smem + buf * SH::STAGE;
+        const unsigned char* Wt = X + SH::XBYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int choff = ((kk * 4 + lq) ^ (l15 & 7)) << 4;
@@ -266,11 +278,12 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     } else if constexpr (EPI == UCLSTM_EPI_ATOMIC) {
         // split-K partial tile: f32 atomic adds, staged through LDS so that every wave instruction adds 64 consecutive
         // floats of one pixel row (256-byte runs, the full-rate atomic shape of MI355X_MICROARCH "Global float atomics")
-        constexpr int AP = BN + 4;                       // floats per staged pixel row
+        constexpr int AP = TBN + 4;                      // floats per staged pixel row
+        constexpr int RPI = 256 / TBN;                   // pixel rows per sweep of the block
         float* At = (float*)smem;                        // [64 pixels][AP]
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (wpx == half) {
+        for (int blk = 0; blk < SH::WM; ++blk) {
+            if (wpx == blk) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -279,19 +292,21 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
                             make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
             }
             __syncthreads();
-            const int n = n0 + (tid & 127);
+            const int col = tid % TBN;
+            const int n = n0 + col;
             if (n < d.N) {
-                for (int pr = tid >> 7; pr < 64; pr += 2) {
-                    const int prow = half * 64 + pr;
+                for (int pr = tid / TBN; pr < 64; pr += RPI) {
+                    const int prow = blk * 64 + pr;
                     if (prow < rows_valid)
-                        __hip_atomic_fetch_add(d.acc_out + (m0 + prow) * (long)d.acc_ld + n, At[pr * AP + (tid & 127)], __ATOMIC_RELAXED,
+                        __hip_atomic_fetch_add(d.acc_out + (m0 + prow) * (long)d.acc_ld + n, At[pr * AP + col], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
         }
     } else {
-        unsigned char* Ot = smem;    // [128 pixels][OT_PITCH]; all K-loop LDS reads retired by the last barrier
+        constexpr int OT_PITCH = SH::OT_PITCH;
+        unsigned char* Ot = smem;    // [TBM pixels][OT_PITCH]; all K-loop LDS reads retired by the last barrier
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int col = wc * 64 + a * 16 + lq * 4;
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
         __syncthreads();
 
-        if (d.stats && tid < BN) {
+        if (d.stats && tid < TBN) {
             const int n = n0 + tid;
             if (n < d.N) {
                 float s1 = 0.f, s2 = 0.f;
@@ -332,9 +347,10 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
             }
         }
 
-        for (int q = tid; q < BM * (BN / 8); q += 256) {
-            const int r = q >> 4;
-            const int cc = q & 15;
+        constexpr int CPR = TBN / 8;                      // 16-byte chunks per staged pixel row
+        for (int q = tid; q < TBM * CPR; q += 256) {
+            const int r = q / CPR;
+            const int cc = q - r * CPR;
             const int n = n0 + cc * 8;
             if (r >= rows_valid || n >= d.N) continue;
             const uint32_t m = (uint32_t)(m0 + r);
@@ -362,12 +378,27 @@ bool src_ok(const uclstm_src& s) {
     return s.ptr && s.C > 0 && (s.C % 8) == 0 && s.Hs > 0 && s.Ws > 0 && ((uintptr_t)s.ptr % 16) == 0;
 }
 
+// block shape: 64 panel rows x 256 pixels when there are at most 64 rows, else 128 x 128
+inline int tile_pixels(int N) { return N <= 64 ? 256 : 128; }
+
+template <int EPI, int WN>
+int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<WN>::SMEM);
+        attr_done = true;
+    }
+    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, WN>), dim3((unsigned)nblk), dim3(256), Shape<WN>::SMEM, st, d, dv);
+    return UCLSTM_OK;
+}
+
 }  // namespace
 
-extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups) {
-    if (groups <= 0 || n_img <= 0 || n_img % groups) return UCLSTM_E_BADARG;
+extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups, int32_t N) {
+    if (groups <= 0 || n_img <= 0 || n_img % groups || N <= 0) return UCLSTM_E_BADARG;
     const int64_t mg = (int64_t)(n_img / groups) * H * W;
-    return (int32_t)((mg + BM - 1) / BM);
+    const int bm = tile_pixels(N);
+    return (int32_t)((mg + bm - 1) / bm);
 }
 
 extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
@@ -390,10 +421,12 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
+    const bool narrow = d.N <= 64 && d.epi != UCLSTM_EPI_LSTM;
+    const int bm = narrow ? 256 : 128, bn = narrow ? 64 : 128;
     dv.Mg = (int)mg;
-    dv.tpg = (int)((mg + BM - 1) / BM);
+    dv.tpg = (int)((mg + bm - 1) / bm);
     dv.n_mtiles = d.groups * dv.tpg;
-    dv.n_ntiles = (d.N + BN - 1) / BN;
+    dv.n_ntiles = (d.N + bn - 1) / bn;
     dv.ksplit = 1;
     dv.kper = dv.ksteps;
     if (d.epi == UCLSTM_EPI_ATOMIC) {
@@ -422,19 +455,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
         return UCLSTM_E_BADARG;
     }
 
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<UCLSTM_EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<UCLSTM_EPI_LSTM>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<UCLSTM_EPI_ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        attr_done = true;
-    }
     hipStream_t st = (hipStream_t)stream;
-    if (d.epi == UCLSTM_EPI_LSTM)
-        UCLSTM_LAUNCH(igemm_fwd_kernel<UCLSTM_EPI_LSTM>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
-    else if (d.epi == UCLSTM_EPI_ATOMIC)
-        UCLSTM_LAUNCH(igemm_fwd_kernel<UCLSTM_EPI_ATOMIC>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
-    else
-        UCLSTM_LAUNCH(igemm_fwd_kernel<UCLSTM_EPI_STORE>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, d, dv);
-    return UCLSTM_OK;
+    if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 2>(d, dv, nblk, st);
+    if (d.epi == UCLSTM_EPI_ATOMIC) return narrow ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 2>(d, dv, nblk, st);
+    return narrow ? launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_STORE, 2>(d, dv, nblk, st);
 }

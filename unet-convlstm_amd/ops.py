@@ -474,7 +474,7 @@ class ConvBNReLU(torch.autograd.Function):
         out = torch.empty((n_img, H, W, Cop), dtype=BF16, device=dev)
         ppg = (n_img // groups) * H * W
         if training:
-            tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups)
+            tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups, Cop)
             stats = torch.empty((groups, tpg, Cop, 2), dtype=F32, device=dev)
             z = out
             igemm_store(srcs, wp, (H, W), n_img, [(z, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=groups, bias=bp, stats=stats)
