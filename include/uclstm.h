@@ -200,7 +200,7 @@ int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const 
                                   void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
 /* Gate nonlinearities + cell update (train/unet.py:29-35) for the split-K form of the cell: `pre` is the f32
  * pre-activation [pixels][N] in the gate-interleaved panel-row order (N = 64*ceil(Hd/16)), bias in the same order. */
-int32_t uclstm_lstm_fwd_pointwise(const float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
+int32_t uclstm_lstm_fwd_pointwise(float* pre /* consumed: read, then cleared to 0 for the next step's accumulation */, const float* bias, const float* c_prev, float* c_out, void* h_out,
                                   void* gates_out, int64_t pixels, int32_t Hd_p, void* stream);
 
 /* ------------------------------------------------------------------------------------ */

@@ -294,7 +294,7 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // ---------------------------------------------------------------------------------------------
 // Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
 // (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
-__global__ void lstm_fwd_pw_kernel(const float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ c_prev,
+__global__ void lstm_fwd_pw_kernel(float* pre, const float* __restrict__ bias, const float* __restrict__ c_prev,
                                    float* __restrict__ c_out, bf16* __restrict__ h_out, bf16* __restrict__ gates_out, int64_t items,
                                    FastDiv dq, int Hd_p, int N) {
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
@@ -306,6 +306,8 @@ __global__ void lstm_fwd_pw_kernel(const float* __restrict__ pre, const float* _
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
             const float4 v = *(const float4*)(pp + gate * 16);
+            // consume-and-clear: the split-K GEMM of the next timestep accumulates into this buffer again
+            *(float4*)(const_cast<float*>(pp) + gate * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 b = bias ? *(const float4*)(bias + nb + gate * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             g4[gate][0] = v.x + b.x; g4[gate][1] = v.y + b.y; g4[gate][2] = v.z + b.z; g4[gate][3] = v.w + b.w;
         }
@@ -335,7 +337,7 @@ __global__ void lstm_fwd_pw_kernel(const float* __restrict__ pre, const float* _
 }
 
 __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
-                                   const uint4* __restrict__ dh_a, const void* __restrict__ dh_b, int dh_b_is_f32,
+                                   const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32,
                                    float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
     const int cpc = dcpc.d;
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
@@ -358,8 +360,16 @@ __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float*
         if (dh_a) unpack8(dh_a[idx], dh);
         if (dh_b) {
             float t[8];
-            if (dh_b_is_f32) load8f((const float*)dh_b + idx * 8, t);
-            else unpack8(((const uint4*)dh_b)[idx], t);
+            if (dh_b_is_f32) {
+                float* p32 = (float*)const_cast<void*>(dh_b) + idx * 8;
+                load8f(p32, t);
+                if (dh_b_is_f32 == 2) {     // consume-and-clear (split-K accumulator reused two timesteps later)
+                    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    store8f(p32, z8);
+                }
+            } else {
+                unpack8(((const uint4*)dh_b)[idx], t);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) dh[i] += t[i];
         }
@@ -694,7 +704,7 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, 
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_lstm_fwd_pointwise(const float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
+extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
                                              void* gates_out, int64_t pixels, int32_t Hd_p, void* stream) {
     if (!aligned16(pre) || !aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
     if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return UCLSTM_E_BADARG;

@@ -303,10 +303,56 @@ def wgrad_splits(n_tiles: int, pixels: int) -> int:
     return max(1, min(target, (pixels + 255) // 256))
 
 
+class ZeroArena:
+    """Bump allocator over one f32 buffer that is zero-filled ONCE per training step.
+
+    Every weight-gradient GEMM accumulates into a zeroed f32 panel; allocating each with ``torch.zeros`` costs one
+    ~6 us fill launch per weight (~25 per step).  ``engine.train_step`` calls ``reset()`` once, which zero-fills
+    last step's demand in a single memset; ``take`` then hands out slices.  Outside a step (tests, ad-hoc calls) or
+    when demand grows, ``take`` falls back to ``torch.zeros``."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.off = 0          # demand counted in the current step (elements)
+        self.zeroed = 0       # elements of buf known to be zero and not yet handed out
+
+    def reset(self, device) -> None:
+        need = self.off
+        self.off = 0
+        if need == 0:
+            self.zeroed = 0
+            return
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.empty(int(need * 1.05) + 1024, dtype=F32, device=device)
+        self.buf[:need].zero_()
+        self.zeroed = need
+
+    def take(self, shape, device) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        n_al = (n + 63) // 64 * 64          # keep every slice 256-byte aligned
+        off = self.off
+        self.off += n_al
+        if self.buf is not None and self.buf.device == device and off + n_al <= self.zeroed:
+            return self.buf[off:off + n].view(*shape)
+        return torch.zeros(shape, dtype=F32, device=device)
+
+
+_ARENAS = {}
+
+
+def arena(device) -> ZeroArena:
+    key = str(device)
+    if key not in _ARENAS:
+        _ARENAS[key] = ZeroArena()
+    return _ARENAS[key]
+
+
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
                 pad: int = 0) -> torch.Tensor:
     dev = srcs[0].t.device
-    dwp = torch.zeros((N, Ktot), dtype=F32, device=dev)
+    dwp = arena(dev).take((N, Ktot), dev)
     d = L.WgradDesc()
     d.n_img, d.H, d.W = n_img, out_hw[0], out_hw[1]
     d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
@@ -677,12 +723,12 @@ class ConvLSTMSeq(torch.autograd.Function):
         # gate convolution as split-K partial tiles accumulated in f32 and apply the cell update in a point-wise kernel;
         # otherwise one fused kernel per step (gates never leave registers).
         ksplit = split_k_factor(B * H * W, wp.shape[0], wp.shape[1] // 64)
-        pre = torch.empty((B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
+        # zeroed once: the point-wise kernel clears what it consumes, so every step finds a zero accumulator
+        pre = torch.zeros((B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
             c_prev = c_hist[t] if (c0 is not None or t > 0) else None
             g_t = gates[t] if need_grad else None
             if ksplit > 1:
-                pre.zero_()
                 igemm_atomic([SrcView(x_all[t]), SrcView(h_hist[t])], wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2)
                 L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), _p(bp), _p(c_prev), _p(c_hist[t + 1]), _p(h_hist[t + 1]), _p(g_t),
                                                         B * H * W, Hdp, _stream()), "lstm_fwd_pointwise")
@@ -714,18 +760,20 @@ class ConvLSTMSeq(torch.autograd.Function):
         # f32 atomics into dh (read back as f32 by the next step's point-wise kernel); else a plain bf16 store.
         ksplit = split_k_factor(pixels, ddh.N, ddh.Ktot // 64)
         rec_dtype = F32 if ksplit > 1 else BF16
-        buf = [torch.empty((B, H, W, Hdp), dtype=rec_dtype, device=dev) for _ in range(2)]
+        # split-K accumulators are zeroed once; the point-wise kernel clears the one it consumes (mode 2), and the same
+        # buffer is accumulated into again two timesteps later
+        buf = [(torch.zeros if ksplit > 1 else torch.empty)((B, H, W, Hdp), dtype=rec_dtype, device=dev) for _ in range(2)]
         need_h0 = ctx.needs_input_grad[1]
         for t in range(T - 1, -1, -1):
             c_prev = c_hist[t] if (has_c0 or t > 0) else None
             L.check(L.lib.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
-                                                    _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec), int(ksplit > 1), _p(dc),
+                                                    _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec),
+                                                    2 if ksplit > 1 else 0, _p(dc),
                                                     int(dc_zero), _p(dgates[t]), pixels, Hdp, _stream()), "lstm_bwd_pointwise")
             dc_zero = False
             if t > 0 or need_h0:
                 dh_rec = buf[t & 1]
                 if ksplit > 1:
-                    dh_rec.zero_()
                     igemm_atomic([SrcView(dgates[t])], wd_h, (H, W), B, dh_rec.view(pixels, Hdp), ksplit, ktap=ks, pad=ks // 2)
                 else:
                     igemm_store([SrcView(dgates[t])], wd_h, (H, W), B, [(dh_rec, 0, ddh.N, 0, 1, 0, 0)], ktap=ks, pad=ks // 2)
