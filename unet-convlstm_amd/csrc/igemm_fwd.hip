@@ -17,6 +17,7 @@
 // K-step costs ~1.5 VALU per MFMA instead of 4.4 (measured: the register-staged first version was
 // VALU-issue bound).  Two LDS stages, one barrier per K-step.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -51,7 +52,7 @@ struct Shape {
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
-template <int EPI, int WN>
+template <int EPI, int WN, int NSRC>
 __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
     using SH = Shape<WN>;
     constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR;
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     auto issue_loads = [&](int buf) {
         unsigned char* X = smem + buf * SH::STAGE;
         unsigned char* Wt = X + SH::XBYTES;
-        if (s == 0) issue_src(roff0, vm0, d.src[0], X);
-        else issue_src(roff1, vm1, d.src[1], X);
+        if constexpr (NSRC == 1) {
+            issue_src(roff0, vm0, d.src[0], X);      // straight-line: can be scheduled into the MFMA shadows
+        } else {
+            if (s == 0) issue_src(roff0, vm0, d.src[0], X);
+            else issue_src(roff1, vm1, d.src[1], X);
+        }
         const uint64_t koff = (uint64_t)kstep * (BK * 2);
 #pragma unroll
         for (int i = 0; i < WR; ++i)
@@ -186,30 +191,58 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         // advance cursor
         ++kstep;
         c0 += BK;
-        if (c0 >= (s == 0 ? dv.kseg0 : dv.kseg1)) {
-            c0 = 0;
-            if (++s == d.nsrc) {
-                s = 0;
-                ++tap;
+        if constexpr (NSRC == 1) {
+            const bool wrap = c0 >= dv.kseg0;        // scalar selects, no branch
+            c0 = wrap ? 0 : c0;
+            tap += wrap ? 1 : 0;
+        } else {
+            if (c0 >= (s == 0 ? dv.kseg0 : dv.kseg1)) {
+                c0 = 0;
+                if (++s == d.nsrc) {
+                    s = 0;
+                    ++tap;
+                }
             }
         }
     };
-    auto compute = [&](int buf) {
+    // One K-step.  Program order: fragments of the first 32-deep half, then (ISSUE) the address math + DMA of the NEXT
+    // step, then the MFMAs -- the sched_group_barrier pattern asks the scheduler to slot those VALU/SALU/DMA
+    // instructions into the shadows of the 16-cycle MFMAs instead of running them as a serial prologue of the step
+    // (guide T19; in-order issue per wave means a serial prologue is pure MFMA idle time for this wave).
+    auto step_body = [&](int buf, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
         const unsigned char* X = smem + buf * SH::STAGE;
         const unsigned char* Wt = X + SH::XBYTES;
+        bf16x8 wf[4], xf[4];
+        const int choff0 = ((0 * 4 + lq) ^ (l15 & 7)) << 4;
+        const int choff1 = ((1 * 4 + lq) ^ (l15 & 7)) << 4;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int choff = ((kk * 4 + lq) ^ (l15 & 7)) << 4;
-            bf16x8 wf[4], xf[4];
+        for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff0);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff);
+        for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff0);
+        if constexpr (ISSUE) issue_loads(buf ^ 1);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff);
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        if constexpr (ISSUE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // 4 VALU
+                __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);     // 3 SALU
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read (DMA)
+            }
         }
     };
 
@@ -217,11 +250,12 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     const int nsteps = kstep_end - kstep_begin;      // >= 1 by construction of ksplit
     issue_loads(0);
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) issue_loads((step + 1) & 1);
-        compute(step & 1);
+    for (int step = 0; step + 1 < nsteps; ++step) {
+        step_body(step & 1, std::true_type{});
         __syncthreads();
     }
+    step_body((nsteps - 1) & 1, std::false_type{});
+    __syncthreads();
 
     // ---- epilogue ----
     if constexpr (EPI == UCLSTM_EPI_LSTM) {
@@ -381,15 +415,20 @@ bool src_ok(const uclstm_src& s) {
 // block shape: 64 panel rows x 256 pixels when there are at most 64 rows, else 128 x 128
 inline int tile_pixels(int N) { return N <= 64 ? 256 : 128; }
 
-template <int EPI, int WN>
-int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
+template <int EPI, int WN, int NSRC>
+int32_t launch_n(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<WN>::SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, WN, NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Shape<WN>::SMEM);
         attr_done = true;
     }
-    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, WN>), dim3((unsigned)nblk), dim3(256), Shape<WN>::SMEM, st, d, dv);
+    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, WN, NSRC>), dim3((unsigned)nblk), dim3(256), Shape<WN>::SMEM, st, d, dv);
     return UCLSTM_OK;
+}
+template <int EPI, int WN>
+int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
+    return d.nsrc == 1 ? launch_n<EPI, WN, 1>(d, dv, nblk, st) : launch_n<EPI, WN, 2>(d, dv, nblk, st);
 }
 
 }  // namespace
