@@ -52,8 +52,9 @@ def test_argument_contracts_are_checked_before_launch():
     d.n_img, d.H, d.W, d.groups, d.ktap, d.scale, d.pad, d.nsrc = 4, 8, 8, 3, 3, 1, 1, 1      # 4 % 3 != 0
     assert L.lib.uclstm_igemm_fwd(C.byref(d), None) == -1
     assert L.lib.uclstm_igemm_tiles_per_group(4, 8, 8, 3, 128) == -1
-    assert L.lib.uclstm_igemm_tiles_per_group(640, 64, 64, 20, 128) == 1024
-    assert L.lib.uclstm_igemm_tiles_per_group(640, 64, 64, 20, 64) == 512
+    assert L.lib.uclstm_igemm_tiles_per_group(640, 64, 64, 20, 128) == 1024     # 128 x 128-pixel blocks
+    assert L.lib.uclstm_igemm_tiles_per_group(640, 64, 64, 20, 64) == 512       # narrow panel: 64 x 256-pixel blocks
+    assert L.lib.uclstm_igemm_tiles_per_group(4, 8, 8, 1, 128) == 2             # small layer: 128 x 128-pixel blocks
     assert L.lib.uclstm_bn_apply_relu(None, None, None, None, 10, 10, 8, None) == -1
     assert L.lib.uclstm_maxpool2_fwd(None, None, 1, 4, 4, 8, None) == -1
     assert L.lib.uclstm_adamw_step(None, None, None, None, 10, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1

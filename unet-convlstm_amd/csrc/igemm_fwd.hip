@@ -17,6 +17,7 @@
 // K-step costs ~1.5 VALU per MFMA instead of 4.4 (measured: the register-staged first version was
 // VALU-issue bound).  Two LDS stages, one barrier per K-step.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -38,31 +39,38 @@ struct Derived {
     FastDiv dHW, dW; // pixel index -> (image, y, x)
 };
 
-template <int WN>
+// Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64);
+//                     2 = 128 x 256, waves 2x4 = 512 threads, one block per CU (large layers: 25 % less L2->LDS
+//                         traffic per flop than shape 0)
+template <int SHP>
 struct Shape {
-    static constexpr int WM = 4 / WN;            // waves along pixels
+    static constexpr int WN = SHP == 1 ? 1 : 2;  // waves along panel rows
+    static constexpr int WM = SHP == 0 ? 2 : 4;  // waves along pixels
+    static constexpr int NT = 64 * WN * WM;      // threads per block
+    static constexpr int RS = NT / 8;            // rows covered by one DMA round of the whole block
     static constexpr int TBN = 64 * WN;          // panel rows per tile
     static constexpr int TBM = 64 * WM;          // pixels per tile
-    static constexpr int XR = TBM / 32;          // X rows staged per thread
-    static constexpr int WR = TBN / 32;          // W rows staged per thread
+    static constexpr int XR = TBM / RS;          // X rows staged per thread
+    static constexpr int WR = TBN / RS;          // W rows staged per thread
     static constexpr int XBYTES = TBM * BK * 2;
     static constexpr int WBYTES = TBN * BK * 2;
     static constexpr int STAGE = XBYTES + WBYTES;
-    static constexpr int SMEM = 2 * STAGE;       // 64 KiB (128x128) / 80 KiB (64x256)
+    static constexpr int STAGES = SHP == 2 ? 3 : 2;
+    static constexpr int SMEM = STAGES * STAGE;  // 64 KiB / 80 KiB / 144 KiB
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
-template <int EPI, int WN, int NSRC>
-__global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
-    using SH = Shape<WN>;
-    constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR;
+template <int EPI, int SHP, int NSRC>
+__global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+    using SH = Shape<SHP>;
+    constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR, NT = SH::NT, RS = SH::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = (WN == 2) ? (wave >> 1) : 0;      // wave position along panel rows
-    const int wpx = (WN == 2) ? (wave & 1) : wave;   // wave position along pixels
+    const int wc = wave / SH::WM;                    // wave position along panel rows
+    const int wpx = wave - wc * SH::WM;              // wave position along pixels
     const int l15 = lane & 15;
     const int lq = lane >> 4;
 
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     uint32_t vm0[XR], vm1[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-        const int r = lrow0 + 32 * i;
+        const int r = lrow0 + RS * i;
         const bool rvalid = r < rows_valid;
         const uint32_t m = (uint32_t)(m0 + (rvalid ? r : 0));
         const int img = (int)fdiv(m, dv.dHW);
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
     uint64_t wrow[WR];
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-        const int nrow = min(n0 + lrow0 + 32 * i, d.N - 1);
+        const int nrow = min(n0 + lrow0 + RS * i, d.N - 1);
         wrow[i] = (uint64_t)d.wp + ((uint64_t)nrow * (uint64_t)d.Ktot + (uint64_t)(lchunk * 8)) * 2u;
     }
 
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
                          : "v"(hit), "v"((uint32_t)zero_addr), "v"((uint32_t)(zero_addr >> 32))
                          : "vcc");
             const uint64_t addr = ((uint64_t)hi << 32) | lo;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)addr, (lds_ptr)(X + i * 32 * 128 + wrow_lds), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)addr, (lds_ptr)(X + i * RS * 128 + wrow_lds), 16, 0, 0);
         }
     };
     auto issue_loads = [&](int buf) {
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         const uint64_t koff = (uint64_t)kstep * (BK * 2);
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow[i] + koff), (lds_ptr)(Wt + i * 32 * 128 + wrow_lds), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow[i] + koff), (lds_ptr)(Wt + i * RS * 128 + wrow_lds), 16, 0, 0);
         // advance cursor
         ++kstep;
         c0 += BK;
@@ -246,16 +254,37 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
     };
 
-    // ---- main loop: DMA of step s+1 is in flight while step s computes; __syncthreads() drains it (vmcnt(0)) ----
     const int nsteps = kstep_end - kstep_begin;      // >= 1 by construction of ksplit
-    issue_loads(0);
-    __syncthreads();
-    for (int step = 0; step + 1 < nsteps; ++step) {
-        step_body(step & 1, std::true_type{});
+    if constexpr (SH::STAGES == 3) {
+        // ---- 3-stage ring (512-thread shape, one block per CU): the DMA of steps s+1 and s+2 stays in flight ACROSS the
+        // barrier.  Per step: wait until this wave's DMA of stage s has landed (counted vmcnt leaves the younger group in
+        // flight), raw s_barrier (now every wave's part of stage s is in LDS and every wave has finished reading stage
+        // s-1 == s+2 mod 3), refill that stage, compute.  No __syncthreads() here: its fence would drain vmcnt to 0.
+        issue_loads(0);
+        if (nsteps > 1) issue_loads(1);
+        int cur = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XR + WR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nxt = cur == 0 ? 2 : cur - 1;            // (cur + 2) % 3
+            if (step + 2 < nsteps) issue_loads(nxt);
+            step_body(cur, std::false_type{});
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        __syncthreads();                                       // all fragment reads done before the epilogue reuses LDS
+    } else {
+        // ---- 2-stage: DMA of step s+1 is in flight while step s computes; __syncthreads() drains it (vmcnt(0)) ----
+        issue_loads(0);
+        __syncthreads();
+        for (int step = 0; step + 1 < nsteps; ++step) {
+            step_body(step & 1, std::true_type{});
+            __syncthreads();
+        }
+        step_body((nsteps - 1) & 1, std::false_type{});
         __syncthreads();
     }
-    step_body((nsteps - 1) & 1, std::false_type{});
-    __syncthreads();
 
     // ---- epilogue ----
     if constexpr (EPI == UCLSTM_EPI_LSTM) {
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         // split-K partial tile: f32 atomic adds, staged through LDS so that every wave instruction adds 64 consecutive
         // floats of one pixel row (256-byte runs, the full-rate atomic shape of MI355X_MICROARCH "Global float atomics")
         constexpr int AP = TBN + 4;                      // floats per staged pixel row
-        constexpr int RPI = 256 / TBN;                   // pixel rows per sweep of the block
+        constexpr int RPI = NT / TBN;                    // pixel rows per sweep of the block
         float* At = (float*)smem;                        // [64 pixels][AP]
 #pragma unroll
         for (int blk = 0; blk < SH::WM; ++blk) {
@@ -382,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd_kernel(const uclstm_igemm_de
         }
 
         constexpr int CPR = TBN / 8;                      // 16-byte chunks per staged pixel row
-        for (int q = tid; q < TBM * CPR; q += 256) {
+        for (int q = tid; q < TBM * CPR; q += NT) {
             const int r = q / CPR;
             const int cc = q - r * CPR;
             const int n = n0 + cc * 8;
@@ -412,23 +441,37 @@ bool src_ok(const uclstm_src& s) {
     return s.ptr && s.C > 0 && (s.C % 8) == 0 && s.Hs > 0 && s.Ws > 0 && ((uintptr_t)s.ptr % 16) == 0;
 }
 
-// block shape: 64 panel rows x 256 pixels when there are at most 64 rows, else 128 x 128
-inline int tile_pixels(int N) { return N <= 64 ? 256 : 128; }
+// Block shape for a launch (also fixes the row count of the BatchNorm partial-sum buffer, so it depends only on what
+// uclstm_igemm_tiles_per_group is told): narrow panels -> 64x256; large plain convolutions -> 128x256; else 128x128.
+inline int pick_shape(int N, int64_t mg, int groups, int epi) {
+    if (epi == UCLSTM_EPI_LSTM) return 0;
+    if (N <= 64) return 1;
+    if (epi != UCLSTM_EPI_STORE) return 0;
+    // Shape 2 (128x256, 512 threads, 3-stage ring with counted vmcnt) is correct but measured 5-12 % SLOWER than shape 0
+    // on every layer of the benchmark model (profiles/round1_notes.md): with 64-wide K-steps the kernels are bound by the
+    // per-CU global->LDS intake (~50 GB/s/CU = 64 flop/B at 128x128), and a 1.33x fatter tile does not pay for an 8-wave
+    // barrier.  It stays compiled as the skeleton of the 256x256 tile planned next; UCLSTM_FWD_SHAPE2=1 selects it.
+    static const bool want2 = [] { const char* e = getenv("UCLSTM_FWD_SHAPE2"); return e && e[0] == '1'; }();
+    const int64_t tiles128 = ((mg + 127) / 128) * groups * ((N + 127) / 128);
+    return (want2 && mg >= 256 && tiles128 >= 1024) ? 2 : 0;
+}
+inline int shape_pixels(int shp) { return shp == 0 ? 128 : 256; }
+inline int shape_rows(int shp) { return shp == 1 ? 64 : 128; }
 
-template <int EPI, int WN, int NSRC>
+template <int EPI, int SHP, int NSRC>
 int32_t launch_n(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, WN, NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Shape<WN>::SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, SHP, NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Shape<SHP>::SMEM);
         attr_done = true;
     }
-    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, WN, NSRC>), dim3((unsigned)nblk), dim3(256), Shape<WN>::SMEM, st, d, dv);
+    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, SHP, NSRC>), dim3((unsigned)nblk), dim3(Shape<SHP>::NT), Shape<SHP>::SMEM, st, d, dv);
     return UCLSTM_OK;
 }
-template <int EPI, int WN>
+template <int EPI, int SHP>
 int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
-    return d.nsrc == 1 ? launch_n<EPI, WN, 1>(d, dv, nblk, st) : launch_n<EPI, WN, 2>(d, dv, nblk, st);
+    return d.nsrc == 1 ? launch_n<EPI, SHP, 1>(d, dv, nblk, st) : launch_n<EPI, SHP, 2>(d, dv, nblk, st);
 }
 
 }  // namespace
@@ -436,7 +479,7 @@ int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipS
 extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups, int32_t N) {
     if (groups <= 0 || n_img <= 0 || n_img % groups || N <= 0) return UCLSTM_E_BADARG;
     const int64_t mg = (int64_t)(n_img / groups) * H * W;
-    const int bm = tile_pixels(N);
+    const int bm = shape_pixels(pick_shape(N, mg, groups, UCLSTM_EPI_STORE));
     return (int32_t)((mg + bm - 1) / bm);
 }
 
@@ -460,8 +503,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
-    const bool narrow = d.N <= 64 && d.epi != UCLSTM_EPI_LSTM;
-    const int bm = narrow ? 256 : 128, bn = narrow ? 64 : 128;
+    const int shp = pick_shape(d.N, mg, d.groups, d.epi);
+    const int bm = shape_pixels(shp), bn = shape_rows(shp);
     dv.Mg = (int)mg;
     dv.tpg = (int)((mg + bm - 1) / bm);
     dv.n_mtiles = d.groups * dv.tpg;
@@ -495,7 +538,9 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     }
 
     hipStream_t st = (hipStream_t)stream;
-    if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 2>(d, dv, nblk, st);
-    if (d.epi == UCLSTM_EPI_ATOMIC) return narrow ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 2>(d, dv, nblk, st);
-    return narrow ? launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_STORE, 2>(d, dv, nblk, st);
+    if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
+    if (d.epi == UCLSTM_EPI_ATOMIC) return shp == 1 ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 0>(d, dv, nblk, st);
+    if (shp == 1) return launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st);
+    if (shp == 2) return launch<UCLSTM_EPI_STORE, 2>(d, dv, nblk, st);
+    return launch<UCLSTM_EPI_STORE, 0>(d, dv, nblk, st);
 }
