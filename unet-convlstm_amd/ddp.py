@@ -55,25 +55,47 @@ class FlatDDP:
         self._hooks = []
         for i, p in enumerate(flat.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        # weight gradients that the operators accumulate on their side stream never pass through autograd's accumulator:
+        # they announce themselves through ops.GRAD_SIDE_HOOKS (called with the side stream current)
+        self._index_of = {id(p): i for i, p in enumerate(flat.params)}
+        if flat.flat_g.is_cuda:
+            from . import ops
+            self._side_hook = lambda param: self._on_ready(self._index_of[id(param)]) if id(param) in self._index_of else None
+            ops.GRAD_SIDE_HOOKS.append(self._side_hook)
+        self._main_stream = None
         self.reset()
+
+    def _on_ready(self, i: int) -> None:
+        bi = self.bucket_of[i]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
 
     def _make_hook(self, i: int):
         def hook(_param):
-            bi = self.bucket_of[i]
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            self._on_ready(i)
         return hook
 
     def _launch(self, bi: int) -> None:
         lo, hi = self.ranges[bi]
-        # gradients are produced on the compute stream; the collective's stream waits on it internally
-        self._handles[bi] = dist.all_reduce(self.flat.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        g = self.flat.flat_g
+        if g.is_cuda:
+            # a bucket mixes gradients produced on the main stream (autograd accumulation) and on the operators' side
+            # stream (weight-gradient GEMMs): the launching stream waits for the other one; the collective's own stream
+            # then orders itself after the launching stream
+            from . import ops
+            cur = torch.cuda.current_stream(g.device)
+            for other in (self._main_stream, ops.side_stream(g.device)):
+                if other is not None and other != cur:
+                    cur.wait_stream(other)
+        self._handles[bi] = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def reset(self) -> None:
-        """Call before each backward (after zero_grad)."""
+        """Call before each backward (after zero_grad), on the stream that will run the backward pass."""
         self._pending = [len(b) for b in self.buckets]
         self._handles = [None] * len(self.buckets)
+        if self.flat.flat_g.is_cuda:
+            self._main_stream = torch.cuda.current_stream(self.flat.flat_g.device)
 
     def finalize(self) -> None:
         """Call after backward, before the optimiser step: launches buckets whose hooks did not all fire
@@ -90,6 +112,11 @@ class FlatDDP:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if getattr(self, "_side_hook", None) is not None:
+            from . import ops
+            if self._side_hook in ops.GRAD_SIDE_HOOKS:
+                ops.GRAD_SIDE_HOOKS.remove(self._side_hook)
+            self._side_hook = None
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)

@@ -9,6 +9,7 @@ tensors: ``_dev`` raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -224,6 +225,63 @@ def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> tor
     grad = torch.empty_like(like, dtype=F32, memory_format=torch.contiguous_format)
     L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), _p(grad), 0, _stream()), "unpack_wgrad")
     return grad
+
+
+# ---------------------------------------------------------------------------------------------
+# weight gradients on a side stream
+# ---------------------------------------------------------------------------------------------
+# The weight-gradient GEMM of a layer is not on the critical path of backward (only the optimiser needs it), while the
+# HBM-bound kernels between the input-gradient GEMMs (BatchNorm backward, pool, point-wise LSTM, packing) leave the MFMA
+# pipes idle.  When the parameter already owns a gradient buffer (``optim.FlatParams`` / ``zero_grad(set_to_none=False)``),
+# the weight-gradient GEMM + its unpack-ACCUMULATE into ``weight.grad`` are enqueued on a second HIP stream and the
+# autograd function returns ``None`` for that parameter; the main stream re-joins at the end of the backward pass
+# (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
+# that a parameter's gradient has been enqueued (the hook runs with the side stream current).
+ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+GRAD_SIDE_HOOKS: list = []
+_SIDE_STREAMS = {}
+_JOIN_PENDING = set()
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _schedule_join(device) -> None:
+    key = str(device)
+    if key in _JOIN_PENDING:
+        return
+    _JOIN_PENDING.add(key)
+
+    def join():
+        _JOIN_PENDING.discard(key)
+        torch.cuda.current_stream(device).wait_stream(side_stream(device))
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[torch.Tensor], run_gemm) -> Optional[torch.Tensor]:
+    """Weight gradient of one layer.  ``run_gemm()`` launches the weight-gradient GEMM and returns the f32 panel.
+    Returns the gradient tensor for autograd, or ``None`` after accumulating into ``weight.grad`` on the side stream."""
+    g = weight.grad
+    if not (ASYNC_WGRAD and g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == weight.shape):
+        return unpack_wgrad(desc, run_gemm(), weight)
+    dev = weight.device
+    main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    side.wait_stream(main)                      # dz / activations produced so far are visible to the side stream
+    with torch.cuda.stream(side):
+        dwp = run_gemm()
+        L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), _p(g), 1, _stream()), "unpack_wgrad(accumulate)")
+        for t in inputs:
+            if t is not None:
+                t.record_stream(side)           # the caching allocator must not recycle them under the side stream
+        for hook in GRAD_SIDE_HOOKS:
+            hook(weight)
+    _schedule_join(dev)
+    return None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -568,13 +626,14 @@ class ConvBNReLU(torch.autograd.Function):
         dy_seg = [(dz, 0, Cop, 0, 1, 0, 0)]
         if im2col:
             pd = im2col_pack_desc(Co, Ci_total, x0.shape[3])
-            dwp = igemm_wgrad([SrcView(x0)], dy_seg, pd.N, pd.Ktot, (H, W), n_img, ktap=1, pad=0)
+            dweight = wgrad_into_param(weight, pd, [x0, dz], lambda: igemm_wgrad([SrcView(x0)], dy_seg, pd.N, pd.Ktot, (H, W), n_img,
+                                                                                 ktap=1, pad=0))
         else:
             c_pad = [x0.shape[3]] + ([x1.shape[3]] if x1 is not None else [])
             pd = conv_pack_desc(Co, Ci_total, list(c_valid), c_pad)
             srcs = [SrcView(x0)] + ([SrcView(x1, off[0], off[1])] if x1 is not None else [])
-            dwp = igemm_wgrad(srcs, dy_seg, pd.N, pd.Ktot, (H, W), n_img, ktap=3, pad=1)
-        dweight = unpack_wgrad(pd, dwp, weight)
+            dweight = wgrad_into_param(weight, pd, [x0, x1, dz], lambda: igemm_wgrad(srcs, dy_seg, pd.N, pd.Ktot, (H, W), n_img,
+                                                                                     ktap=3, pad=1))
 
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] and not im2col:
@@ -642,8 +701,7 @@ class ConvT2x2(torch.autograd.Function):
         N, h, w, _ = x.shape
         pd = convt_pack_desc(Ci, Co)
         segs = [(du, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
-        dwp = igemm_wgrad([SrcView(x)], segs, pd.N, pd.Ktot, (h, w), N, ktap=1, pad=0)
-        dweight = unpack_wgrad(pd, dwp, weight)
+        dweight = wgrad_into_param(weight, pd, [x, du], lambda: igemm_wgrad([SrcView(x)], segs, pd.N, pd.Ktot, (h, w), N, ktap=1, pad=0))
         dbias = colsum(du)[:Co].contiguous() if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -781,9 +839,9 @@ class ConvLSTMSeq(torch.autograd.Function):
         x_flat = x_all.reshape(T * B, H, W, Cxp)
         hprev_flat = h_hist[:T].reshape(T * B, H, W, Hdp)
         ud = lstm_wgrad_unpack_desc(Hd, Cx, ks)
-        dwp = igemm_wgrad([SrcView(x_flat), SrcView(hprev_flat)], [(dg_flat, 0, 4 * Hdp, 0, 1, 0, 0)], ud.N, ud.Ktot, (H, W), T * B,
-                          ktap=ks, pad=ks // 2)
-        dweight = unpack_wgrad(ud, dwp, weight)
+        dweight = wgrad_into_param(weight, ud, [x_all, h_hist, dgates],
+                                   lambda: igemm_wgrad([SrcView(x_flat), SrcView(hprev_flat)], [(dg_flat, 0, 4 * Hdp, 0, 1, 0, 0)],
+                                                       ud.N, ud.Ktot, (H, W), T * B, ktap=ks, pad=ks // 2))
         dbias = None
         if has_bias:
             cs = colsum(dg_flat).view(4, Hdp)[:, :Hd]
