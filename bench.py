@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-skip-lstm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in FlatDDP even for one rank (exercises the RCCL path)")
     ap.add_argument("--dump-launches", action="store_true", help="per-shape table of the instrumented step (stderr)")
     return ap.parse_args()
 
@@ -92,8 +93,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or a.force_ddp:
+        if "RANK" not in os.environ:                      # single process without torchrun
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import unet_convlstm_amd as U
     from unet_convlstm_amd import ops
@@ -102,7 +108,7 @@ def main():
     torch.manual_seed(1234)
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
     opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
-    ddp = U.FlatDDP(model, opt.flat) if world > 1 else None
+    ddp = U.FlatDDP(model, opt.flat) if (world > 1 or a.force_ddp) else None
     data = U.SyntheticSequences(a.batch, a.seq, a.size, a.size, seed=1 + rank, kind="uniform", device=dev)
     x, y = data.x, data.y
 
@@ -174,7 +180,8 @@ def main():
     if rank == 0:
         gf = TRAIN_GFLOP_PER_FRAME.get((a.base_ch, skip, a.size))
         out = {
-            "metric": "training frames/sec, Moving-MNIST 64x64 seq-20",
+            "metric": ("training frames/sec, Moving-MNIST 64x64 seq-20" if (a.size, a.seq) == (64, 20)
+                       else f"training frames/sec, {a.size}x{a.size} seq-{a.seq}"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -191,7 +198,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_ddp:
         dist.destroy_process_group()
 
 

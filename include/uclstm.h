@@ -252,6 +252,20 @@ int32_t uclstm_sumsq(const float* g, int64_t n, double* out /* accumulates, call
 int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Data path around the step                              */
+/* ------------------------------------------------------------------------------------ */
+/* NPZSequenceDataset.__getitem__ (train/unet.py:273-304) for n_frames = batch*T frames on device: mask = raw x channel 0
+ * > 1.1 (BEFORE scaling, :279), x = x_raw / norm_const (:283), y = 2*(asinh(clip(y_raw)/y_scale) - trans_min)/(trans_max -
+ * trans_min) - 1 (:287-299).  x_raw/x: f32 [n_frames][C][HW]; y_raw/y/mask: f32 [n_frames][HW]. */
+int32_t uclstm_dataset_transform(const float* x_raw, const float* y_raw, float* x, float* y, float* mask, int64_t n_frames,
+                                 int32_t C, int32_t HW, float norm_const, float min_vel, float max_vel, int32_t clip,
+                                 float y_scale, float trans_min, float trans_max, void* stream);
+/* Epoch metric block of main.py:114-142 as running sums: sums[0..3] += sum|d|m, sum d^2 m, sum d m, sum m with
+ * d = denormalize(y_pred) - denormalize(y) (train/unet.py:316-319, asinh transform); mask may be NULL. */
+int32_t uclstm_metric_sums(const float* y_pred, const float* y, const float* mask, double* sums, int64_t n, float y_scale,
+                           float trans_min, float trans_max, void* stream);
+
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);
 const char* uclstm_build_arch(void);

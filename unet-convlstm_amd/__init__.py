@@ -14,9 +14,9 @@ from .modules import (ConvLSTMCell, ConvLSTM, DoubleConv, Down, Up, OutConv, Spa
                       TemporalUNetDualView, UNet)
 from .loss import compute_loss
 from .optim import FusedAdamW
-from .engine import train_one_epoch, evaluate, train_step, SyntheticSequences, NPZSequenceDataset
+from .engine import train_one_epoch, evaluate, train_step, SyntheticSequences, NPZSequenceDataset, device_transform
 from .ddp import FlatDDP
 
 __all__ = ["ConvLSTMCell", "ConvLSTM", "DoubleConv", "Down", "Up", "OutConv", "SpatialAttention",
            "TemporalUNetDualView", "UNet", "compute_loss", "FusedAdamW", "train_one_epoch", "evaluate",
-           "train_step", "SyntheticSequences", "NPZSequenceDataset", "FlatDDP", "UclstmError", "ops"]
+           "train_step", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "UclstmError", "ops"]

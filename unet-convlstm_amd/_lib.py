@@ -105,6 +105,8 @@ _PROTOS = {
     "uclstm_loss_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "uclstm_sumsq": [_P, _L, _P, _P],
     "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
+    "uclstm_dataset_transform": [_P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _F, _F, _F, _P],
+    "uclstm_metric_sums": [_P, _P, _P, _P, _L, _F, _F, _F, _P],
     "uclstm_abi_version": [],
     "uclstm_build_arch": [],
     "uclstm_last_error_string": [],

@@ -132,6 +132,46 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
     }
 }
 
+// NPZSequenceDataset.__getitem__ for a batch (train/unet.py:273-304): mask from RAW channel 0 (> 1.1) before scaling,
+// x / norm_const, y clipped -> asinh(y / scale) -> [-1, 1]
+__global__ void dataset_transform_kernel(const float* __restrict__ xr, const float* __restrict__ yr, float* __restrict__ x,
+                                         float* __restrict__ y, float* __restrict__ mask, int64_t total, FastDiv dHW, int C, float inv_norm,
+                                         float min_vel, float max_vel, int clip, float inv_yscale, float tmin, float inv_trange) {
+    const int HW = dHW.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t f = fdiv((uint32_t)idx, dHW);               // frame
+        const uint32_t pix = (uint32_t)idx - f * HW;
+        const float* xf = xr + (int64_t)f * C * HW + pix;
+        mask[idx] = xf[0] > 1.1f ? 1.f : 0.f;
+        for (int c = 0; c < C; ++c) x[(int64_t)f * C * HW + (int64_t)c * HW + pix] = xf[(int64_t)c * HW] * inv_norm;
+        float v = yr[idx];
+        if (clip) v = fminf(fmaxf(v, min_vel), max_vel);
+        y[idx] = 2.f * (asinhf(v * inv_yscale) - tmin) * inv_trange - 1.f;
+    }
+}
+
+// Epoch metrics of main.py:114-142 as running sums: de-normalise (train/unet.py:316-319) prediction and target,
+// d = pred - target, sums += (sum |d| m, sum d^2 m, sum d m, sum m)
+__global__ void metric_sums_kernel(const float* __restrict__ yp, const float* __restrict__ y, const float* __restrict__ mask,
+                                   double* __restrict__ sums, int64_t n, float yscale, float tmin, float trange) {
+    __shared__ double red[16];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float a = sinhf((yp[i] + 1.f) * 0.5f * trange + tmin) * yscale;
+        const float b = sinhf((y[i] + 1.f) * 0.5f * trange + tmin) * yscale;
+        const float m = mask ? (mask[i] != 0.f ? 1.f : 0.f) : 1.f;
+        const double d = (double)(a - b);
+        acc[0] += fabs(d) * m;
+        acc[1] += d * d * m;
+        acc[2] += d * m;
+        acc[3] += m;
+    }
+    block_sum<4>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(sums + k, acc[k]);
+}
+
 int grid_for(int64_t items, int cap) {
     int64_t b = (items + NT - 1) / NT;
     if (b > cap) b = cap;
@@ -173,6 +213,28 @@ extern "C" int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     UCLSTM_LAUNCH(adamw_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_dataset_transform(const float* x_raw, const float* y_raw, float* x, float* y, float* mask, int64_t n_frames,
+                                            int32_t C, int32_t HW, float norm_const, float min_vel, float max_vel, int32_t clip,
+                                            float y_scale, float trans_min, float trans_max, void* stream) {
+    if (!x_raw || !y_raw || !x || !y || !mask || n_frames <= 0 || C <= 0 || HW <= 0 || norm_const == 0.f || y_scale == 0.f ||
+        trans_max == trans_min)
+        return UCLSTM_E_BADARG;
+    const int64_t total = n_frames * HW;
+    if (total >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(dataset_transform_kernel, dim3(grid_for(total, 2048)), dim3(NT), 0, (hipStream_t)stream, x_raw, y_raw, x, y, mask, total,
+                  make_fastdiv(HW), C, 1.0f / norm_const, min_vel, max_vel, clip, 1.0f / y_scale, trans_min,
+                  1.0f / (trans_max - trans_min));
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_metric_sums(const float* y_pred, const float* y, const float* mask, double* sums, int64_t n, float y_scale,
+                                      float trans_min, float trans_max, void* stream) {
+    if (!y_pred || !y || !sums || n <= 0) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(metric_sums_kernel, dim3(grid_for(n, 1024)), dim3(NT), 0, (hipStream_t)stream, y_pred, y, mask, sums, n, y_scale,
+                  trans_min, trans_max - trans_min);
     return UCLSTM_OK;
 }
 

@@ -142,6 +142,25 @@ class NPZSequenceDataset(torch.utils.data.Dataset):
         return yt
 
 
+def device_transform(ds, x_raw: torch.Tensor, y_raw: torch.Tensor):
+    """``NPZSequenceDataset.__getitem__`` (train/unet.py:273-304) for a whole RAW batch already on the device:
+    ``x_raw [B,T,C,H,W]``, ``y_raw [B,T,1,H,W]`` f32 -> ``(x, y, mask)`` exactly as the host dataset would yield them
+    (asinh transform only).  One kernel; lets the loader ship raw ``.npz`` slabs and skip the per-item numpy work."""
+    from . import _lib as L
+    if ds.y_transform != "asinh":
+        raise ValueError("device_transform implements the 'asinh' target transform (the reference default)")
+    x_raw = ops._dev(x_raw.contiguous(), torch.float32, "x_raw")
+    y_raw = ops._dev(y_raw.contiguous(), torch.float32, "y_raw")
+    B, T, Cc, H, W = x_raw.shape
+    x, y = torch.empty_like(x_raw), torch.empty_like(y_raw)
+    mask = torch.empty_like(y_raw)
+    L.check(L.lib.uclstm_dataset_transform(ops._p(x_raw), ops._p(y_raw), ops._p(x), ops._p(y), ops._p(mask), B * T, Cc, H * W,
+                                           float(ds.norm_const), float(ds.min_vel), float(ds.max_vel), int(bool(ds.clip_outliers)),
+                                           float(ds.y_scale), float(ds.trans_min), float(ds.trans_max), ops._stream()),
+            "dataset_transform")
+    return x, y, mask
+
+
 # ---------------------------------------------------------------------------------------------
 # step / epoch loops
 # ---------------------------------------------------------------------------------------------
@@ -178,6 +197,16 @@ class _Metrics:
 
     @torch.no_grad()
     def add(self, dataset_obj, y, y_pred, mask, use_mask):
+        if y_pred.is_cuda and getattr(dataset_obj, "y_transform", None) == "asinh" and hasattr(dataset_obj, "trans_min"):
+            # one fused kernel: de-normalise both, difference, masked running sums (no intermediate tensors)
+            from . import _lib as L
+            yp = y_pred.contiguous().float()
+            yt = y.contiguous().float()
+            m = mask.contiguous().float() if (use_mask and mask is not None) else None
+            L.check(L.lib.uclstm_metric_sums(ops._p(yp), ops._p(yt), ops._p(m), ops._p(self.s), yp.numel(),
+                                             float(dataset_obj.y_scale), float(dataset_obj.trans_min), float(dataset_obj.trans_max),
+                                             ops._stream()), "metric_sums")
+            return
         d = (dataset_obj.denormalize(y_pred) - dataset_obj.denormalize(y)).double()
         if use_mask:
             m = (mask != 0).double()
