@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in FlatDDP even for one rank (exercises the RCCL path)")
+    ap.add_argument("--mode", default="train", choices=["train", "rollout"],
+                    help="rollout = BASELINE.json config 5: stateful frame-by-frame inference, hipGraph-captured step")
+    ap.add_argument("--no-graph", action="store_true", help="rollout without graph capture")
     ap.add_argument("--dump-launches", action="store_true", help="per-shape table of the instrumented step (stderr)")
     return ap.parse_args()
 
@@ -81,6 +84,32 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def rollout_bench(a, U, dev, skip):
+    """Inference-only autoregressive rollout (config 5): one frame per step, all recurrent state carried on the device."""
+    model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip).to(dev).eval()
+    sp = U.StreamingPredictor(model, use_graph=not a.no_graph, warmup=2)
+    frames = [torch.rand(a.batch, 2, a.size, a.size, device=dev) for _ in range(4)]
+    for i in range(max(a.warmup, 3)):                 # eager warm-up + capture + first replay
+        sp.step(frames[i % 4])
+    torch.cuda.synchronize()
+    n = a.steps * a.seq
+    t0 = time.perf_counter()
+    for i in range(n):
+        y = sp.step(frames[i % 4])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd_gf = {64: 13.264, 128: 53.06, 256: 212.22, 512: 848.89}.get(a.size) if (a.base_ch, skip) == (64, True) else None
+    out = {"metric": f"inference frames/sec, {a.size}x{a.size} stateful rollout", "value": round(a.batch * n / dt, 2), "unit": "frames/s",
+           "n_gpus": 1, "steps": n, "warmup": max(a.warmup, 3), "ms_per_step": round(dt / n * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) eval, frame-by-frame, "
+                                  f"batch {a.batch}, hipGraph={'off' if a.no_graph else 'on'}"},
+           "finite": bool(torch.isfinite(y).all())}
+    if fwd_gf:
+        out["model_tflops"] = round(out["value"] * fwd_gf / 1e3, 2)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,6 +135,8 @@ def main():
 
     skip = not a.no_skip_lstm
     torch.manual_seed(1234)
+    if a.mode == "rollout":
+        return rollout_bench(a, U, dev, skip)
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
     opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
     ddp = U.FlatDDP(model, opt.flat) if (world > 1 or a.force_ddp) else None

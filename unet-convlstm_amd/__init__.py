@@ -16,7 +16,8 @@ from .loss import compute_loss
 from .optim import FusedAdamW
 from .engine import train_one_epoch, evaluate, train_step, SyntheticSequences, NPZSequenceDataset, device_transform
 from .ddp import FlatDDP
+from .streaming import StreamingPredictor
 
 __all__ = ["ConvLSTMCell", "ConvLSTM", "DoubleConv", "Down", "Up", "OutConv", "SpatialAttention",
            "TemporalUNetDualView", "UNet", "compute_loss", "FusedAdamW", "train_one_epoch", "evaluate",
-           "train_step", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "UclstmError", "ops"]
+           "train_step", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "StreamingPredictor", "UclstmError", "ops"]

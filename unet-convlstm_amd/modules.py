@@ -313,4 +313,28 @@ class TemporalUNetDualView(nn.Module):
         return out_seq, new_state
 
 
+    # -- streaming: one frame in, one frame out, ALL recurrent states carried (API superset of the reference, whose
+    #    forward() drops the skip-LSTM states, train/unet.py:190-191)
+    def step_nhwc(self, x_t: Tensor, full_state: Optional[dict] = None):
+        """``x_t`` f32 ``[B, 2*in_channels_per_sat, H, W]`` -> ``(y_t f32 [B,out,H,W], full_state)``.
+
+        ``full_state`` maps ``'temporal'/'skip3'/'skip2'`` to per-layer ``(h bf16 NHWC, c f32 NHWC)`` lists; ``None`` is the
+        zero state.  Feeding frames one by one reproduces ``forward()`` on the whole sequence, skip LSTMs included."""
+        c = self.base_ch
+        st = full_state or {}
+        xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
+        b_all, st_t = self.temporal.seq_nhwc(xb.unsqueeze(0), st.get("temporal"))
+        new_state = {"temporal": st_t}
+        if self.use_skip_lstm:
+            x3_l, st3 = self.lstm_skip3.seq_nhwc(x3.unsqueeze(0), st.get("skip3"))
+            x2_l, st2 = self.lstm_skip2.seq_nhwc(x2.unsqueeze(0), st.get("skip2"))
+            x3, x2 = x3_l[0], x2_l[0]
+            new_state["skip3"], new_state["skip2"] = st3, st2
+        d3 = self.up3.forward_nhwc(b_all[0], x3, c * 8, 1)
+        d2 = self.up2.forward_nhwc(d3, x2, c * 4, 1)
+        d1 = self.up1.forward_nhwc(d2, x1, c * 2, 1)
+        d0 = self.up0.forward_nhwc(d1, x0, c, 1)
+        return self.outc.forward_nhwc(d0), new_state
+
+
 UNet = TemporalUNetDualView   # BASELINE.json calls the model "UNet"; the reference class is TemporalUNetDualView

@@ -207,10 +207,31 @@ def convt_dgrad_pack_desc(Ci: int, Co: int) -> L.PackDesc:
     return d
 
 
+# Inference-time panel cache, OFF unless a caller that owns frozen weights turns it on (streaming.StreamingPredictor):
+# removes ~50 pack launches per forward from a rollout.  It cannot be automatic: the fused optimiser updates parameters
+# through raw pointers, which does not bump tensor versions, so only the owner knows the weights are frozen.
+CACHE_PANELS = False
+_PANEL_CACHE: dict = {}
+
+
+def clear_panel_cache() -> None:
+    _PANEL_CACHE.clear()
+
+
 def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0) -> torch.Tensor:
     _dev(w, F32, "weight")
+    key = None
+    if CACHE_PANELS:
+        key = (w.data_ptr(), elem_offset, bytes(desc))
+        hit = _PANEL_CACHE.get(key)
+        if hit is not None and hit[0] == w._version:
+            return hit[1]
     wp = torch.empty((desc.N, desc.Ktot), dtype=BF16, device=w.device)
     L.check(L.lib.uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * elem_offset), _p(wp), _stream()), "pack_weights")
+    if key is not None:
+        if len(_PANEL_CACHE) > 512:
+            _PANEL_CACHE.clear()
+        _PANEL_CACHE[key] = (w._version, wp)
     return wp
 
 
