@@ -112,8 +112,8 @@ int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* d, void* stream);
 
 /* Weight gradient  dWp[n][k] (+)= sum_pixels dY[pixel][n] * A[pixel][k]  (f32 [N][Ktot], same
  * K order as the forward panel).  dY is read through seg[] (nseg >= 1); `splits` pixel ranges
- * accumulate with f32 atomics, so dWp must be zeroed by the caller when splits > 1 or
- * accumulate != 0.  Replaces the autograd weight-gradient of the convolutions above. */
+ * (0 = chosen by the library for its tile shape and the 256 CUs) accumulate with f32 atomics, so dWp
+ * must be zeroed by the caller.  Replaces the autograd weight-gradient of the convolutions above. */
 typedef struct {
     int32_t n_img, H, W;
     int32_t ktap, scale, pad;

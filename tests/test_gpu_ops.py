@@ -196,6 +196,15 @@ def test_conv3x3_padded_second_source_and_groups_stats():
     (2, 136, 0, 72, 6, 7),
     (2, 16, 8, 16, 10, 10),
     (4, 64, 0, 128, 16, 16),
+    # power-of-two images take the buffer-addressed fast path (igemm_wgrad_p2_kernel): both tile shapes, one and two
+    # sources, a 64+64 concat whose 128-column tile straddles the sources, W >= 64 / W < 64 / image smaller than a stage
+    (4, 64, 0, 64, 16, 16),
+    (2, 64, 64, 64, 64, 64),
+    (2, 64, 64, 128, 32, 32),
+    (1, 24, 0, 40, 128, 64),
+    (8, 136, 72, 72, 4, 4),
+    (16, 32, 0, 200, 2, 4),
+    (3, 16, 8, 16, 8, 16),
 ])
 def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
     torch.manual_seed(3)

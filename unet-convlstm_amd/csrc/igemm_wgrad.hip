@@ -17,6 +17,7 @@
 // gradient): operand offsets are linear in the pixel index, only the tap-validity needs (y, x).  The tile is added to
 // dWp with f32 atomics staged through LDS (256 contiguous bytes per wave instruction).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -224,6 +225,259 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const uclstm_wgrad_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path: dense same-size operands (PLAIN), H and W powers of two, one dY segment, 3x3/pad 1 or 1x1/pad 0.
+//
+// Staging goes through BUFFER descriptors (buffer_load_dwordx4 ... lds).  Measured on gfx950 (tools/probes/): a lane
+// whose voffset + soffset is >= num_records writes 16 ZERO bytes into LDS.  So
+//   * a padded tap is one v_cndmask (offset or 0x80000000) instead of a 64-bit select against a zero page;
+//   * the per-lane voffset is loop invariant: the pixel range advances through the SGPR soffset, no address VALU at all;
+//   * a lane whose (tap, channel) column or dY column does not exist carries 0x80000000 for the whole loop.
+// The X descriptor starts (W+1) pixels BEFORE the tensor so that voffset is never negative (those bytes are never
+// fetched: every tap that would reach them is masked).  Tap validity without division: a stage is 64 consecutive pixels
+// starting at a multiple of 64, so with W, H powers of two the row r of the stage has
+//     x = (mb & (W-1)) + (r & (W-1)),    y = ((mb >> lw) + (r >> lw)) & (H-1)
+// and "x + ddx outside" <=> x == one bad value: both tests become a compare of a per-stage SCALAR with a per-lane
+// constant (3 VALU per staged row instead of ~35 in the generic kernel, which was VALU-issue bound at 4.3 VALU/MFMA).
+//
+// LDS image: every operand tile is a set of PLANES of [64 pixels][64 columns] (128-byte rows, 8 KiB).  One DMA
+// instruction fills 8 rows of one plane, so all its lanes share one 64-column segment = one (tap, source): the
+// descriptor is wave-uniform.  32-byte granule g of row r sits at position g ^ ((r>>1)&3); two 128-byte rows share a
+// 256-byte bank row, so the eight row pieces of a transposing read (rows r..r+7) cover all 64 banks.
+// Two tile shapes: WN = 2: 128 panel rows x 128 K columns (waves 2x2);  WN = 1: 64 x 256 (waves 1x4) for C_out <= 64.
+struct P2 {
+    int lw, lh;            // log2 W, log2 H
+    uint32_t ybytes;       // dY tensor bytes
+    uint32_t xbytes[2];    // source bytes + bias
+    uint32_t xbias[2];     // bytes the descriptor base lies before the tensor
+};
+
+constexpr int PLANE = TP * 128;          // 8 KiB
+constexpr uint32_t OOB = 0x80000000u;
+
+template <int WN>
+struct WShape {
+    static constexpr int WK = 4 / WN;
+    static constexpr int TN_ = 64 * WN, TC_ = 64 * WK;
+    static constexpr int NPL = WN + WK;                       // planes per stage (dY planes first)
+    static constexpr int STAGE = NPL * PLANE;                 // 32 KiB / 40 KiB
+    static constexpr int SMEM = 2 * STAGE;
+    static constexpr int NI = 2 * NPL;                        // DMA instructions per wave per stage (8 per plane / 4 waves)
+};
+
+__device__ __forceinline__ bf16x8 tr_frag128(const unsigned char* p) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p + 16 * 128));
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    const short8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int WN, int NSRC>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgrad_desc d, const WDerived dv, const P2 p2) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
+    using SH = WShape<WN>;
+    constexpr int WK = SH::WK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WK;     // along panel rows
+    const int wk = wave % WK;     // along K columns
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+
+    const int per_split = dv.n_kt * dv.n_nt;
+    const int lid = xcd_remap(blockIdx.x, per_split * d.splits);
+    const int sp = lid / per_split;
+    const int rr = lid - sp * per_split;
+    const int kt = rr / dv.n_nt;
+    const int nt = rr - kt * dv.n_nt;
+    const int n0 = nt * SH::TN_;
+    const int kbase = kt * SH::TC_;
+
+    const long m_begin = (long)sp * dv.chunk;
+    if (m_begin >= dv.M) return;     // block-uniform: trailing split with no pixels
+    const long m_end = min(dv.M, m_begin + dv.chunk);
+    const int nsteps = (int)((m_end - m_begin) / TP);        // M % 64 == 0 on this path
+
+    const uclstm_seg G = d.seg[0];
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)G.ptr, 0, p2.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[0].ptr - p2.xbias[0]), 0, p2.xbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx1 =
+        NSRC > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[1].ptr - p2.xbias[1]), 0, p2.xbytes[1], 0x00020000)
+                 : rsx0;
+
+    // ---- staging role: instruction j of wave w = row group 4*(j&1) + w of plane j>>1; lane = (row lane>>3, position lane&7)
+    const int lrow = lane >> 3;
+    const int cp = lane & 7;
+    const int sc = 2 * ((cp >> 1) ^ ((lrow >> 1) & 3)) + (cp & 1);      // source 16-byte chunk stored at this position
+    const int Wm = d.W - 1, Hm = d.H - 1;
+    const int kseg = dv.kseg0 + dv.kseg1;
+
+    uint32_t voff[SH::NI];            // loop-invariant byte offsets (dY planes, then X planes)
+    uint32_t kxj[2 * WK], kyj[2 * WK];
+    int xsrc[WK];                     // wave-uniform source of each X plane
+#pragma unroll
+    for (int j = 0; j < SH::NI; ++j) {
+        const int pl = j >> 1;
+        const int r = 8 * (4 * (j & 1) + wave) + lrow;        // pixel row of the stage
+        if (pl < WN) {
+            const int ny = n0 + pl * 64 + sc * 8;
+            const bool yok = ny < d.N && ny >= G.n_begin && ny < G.n_end;
+            voff[j] = yok ? (uint32_t)(2 * (r * G.C + G.c_off + (ny - G.n_begin))) : OOB;
+        } else {
+            const int xp = pl - WN;
+            const int k0 = kbase + xp * 64;                   // first column of the plane: one (tap, source)
+            const int xtap = (int)fdiv((uint32_t)k0, dv.dPerTap);
+            const int kr = k0 - xtap * kseg;
+            const int xs_ = (NSRC > 1 && kr >= dv.kseg0) ? 1 : 0;
+            const int xc = (xs_ ? kr - dv.kseg0 : kr) + sc * 8;
+            const uclstm_src S = d.src[xs_];
+            const bool xok = k0 < d.Ktot && xc < S.C;
+            const int tdy = xtap / d.ktap;
+            const int ddy = tdy - d.pad;
+            const int ddx = (xtap - tdy * d.ktap) - d.pad;
+            const int badx = ddx < 0 ? 0 : (ddx > 0 ? Wm : -1);
+            const int bady = ddy < 0 ? 0 : (ddy > 0 ? Hm : -1);
+            if ((j & 1) == 0) xsrc[xp] = xs_;
+            voff[j] = xok ? (uint32_t)(2 * (r * S.C + (ddy * S.Ws + ddx) * S.C + xc) + (int)p2.xbias[xs_]) : OOB;
+            // bad column <=> (mb & (W-1)) == kxj ; bad row <=> ((mb >> lw) & (H-1)) == kyj   (0xffffffff: never)
+            const int jj = j - 2 * WN;
+            if (badx < 0) kxj[jj] = 0xffffffffu;
+            else if (d.W >= 64) kxj[jj] = (uint32_t)(badx - r);        // equal only if a non-negative multiple of 64
+            else kxj[jj] = ((r & Wm) == badx) ? 0u : 0xffffffffu;
+            kyj[jj] = bady < 0 ? 0xffffffffu : (uint32_t)((bady - (r >> p2.lw)) & Hm);
+        }
+    }
+    const uint32_t ystep = (uint32_t)(2 * G.C), x0step = (uint32_t)(2 * d.src[0].C), x1step = (uint32_t)(2 * d.src[NSRC - 1].C);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint32_t mb = (uint32_t)m_begin;      // first pixel of the NEXT stage to load (wave-uniform)
+    auto issue_loads = [&](int buf) {
+        unsigned char* St = smem + buf * SH::STAGE;
+        const uint32_t sy = (mb >> p2.lw) & (uint32_t)Hm;
+        const uint32_t sx = mb & (uint32_t)Wm;
+        const uint32_t ysoff = mb * ystep, x0soff = mb * x0step, x1soff = mb * x1step;
+#pragma unroll
+        for (int j = 0; j < SH::NI; ++j) {
+            lds_ptr dst = (lds_ptr)(St + (j >> 1) * PLANE + (4 * (j & 1) + wave) * 1024);
+            if (j < 2 * WN) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, dst, 16, voff[j], ysoff, 0, 0);
+            } else {
+                const int jj = j - 2 * WN;
+                const bool ok = (sx != kxj[jj]) & (sy != kyj[jj]);
+                const uint32_t off = ok ? voff[j] : OOB;
+                if (NSRC == 1 || xsrc[jj >> 1] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx0, dst, 16, off, x0soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx1, dst, 16, off, x1soff, 0, 0);
+            }
+        }
+        mb += TP;
+    };
+
+    // transposing fragment reads (k-permutation as in the generic kernel): same offsets inside every plane
+    const int trow = 4 * lq + (l15 >> 2);
+    int goff[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) goff[a] = trow * 128 + ((a ^ ((trow >> 1) & 3)) << 5) + (l15 & 3) * 8;
+    auto compute = [&](int buf) {
+        const unsigned char* Y = smem + buf * SH::STAGE + wc * PLANE;
+        const unsigned char* X = smem + buf * SH::STAGE + (WN + wk) * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 yf[4], xf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) yf[a] = tr_frag128(Y + ks * 32 * 128 + goff[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[b] = tr_frag128(X + ks * 32 * 128 + goff[b]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    issue_loads(0);
+    __syncthreads();                 // drains the DMA (vmcnt(0)) and orders it before the reads
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) issue_loads((step + 1) & 1);
+        compute(step & 1);
+        __syncthreads();
+    }
+
+    // ---- accumulate the tile into dWp: LDS-staged, 64 consecutive floats of one panel row per wave instruction ----
+    constexpr int TCc = SH::TC_;
+    constexpr int AP = TCc + 4;
+    float* At = (float*)smem;                // [64 panel rows][AP]
+#pragma unroll
+    for (int half = 0; half < WN; ++half) {
+        if (wc == half) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) At[(a * 16 + lq * 4 + r) * AP + wk * 64 + b * 16 + l15] = acc[a][b][r];
+        }
+        __syncthreads();
+        const int col = tid % TCc;
+        const int k = kbase + col;
+        if (k < d.Ktot) {
+            for (int pr = tid / TCc; pr < 64; pr += 256 / TCc) {
+                const int n = n0 + half * 64 + pr;
+                if (n < d.N)
+                    __hip_atomic_fetch_add(d.dwp + (long)n * d.Ktot + k, At[pr * AP + col], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+// Pixel-range splits: minimise (rounds of the 512 resident blocks) x (stages per block + fixed cost of a block's
+// prologue and its 64-KiB atomic epilogue, ~8 stages' worth).
+int auto_splits(int64_t tiles, int64_t stages) {
+    int best = 1;
+    int64_t best_cost = -1;
+    const int64_t smax = stages / 4 > 1 ? stages / 4 : 1;
+    for (int64_t s = 1; s <= smax && tiles * s <= 16384; ++s) {
+        const int64_t per = (stages + s - 1) / s;
+        const int64_t used = (stages + per - 1) / per;      // splits that actually get pixels
+        const int64_t rounds = (tiles * used + 511) / 512;
+        const int64_t cost = rounds * (per + 8);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = (int)s;
+        }
+    }
+    return best;
+}
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+template <int WN, int NSRC>
+int32_t launch_p2(const uclstm_wgrad_desc& d, const WDerived& dv, const P2& p2, int64_t nblk, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_wgrad_p2_kernel<WN, NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   WShape<WN>::SMEM);
+        attr_done = true;
+    }
+    UCLSTM_LAUNCH((igemm_wgrad_p2_kernel<WN, NSRC>), dim3((unsigned)nblk), dim3(256), WShape<WN>::SMEM, st, d, dv, p2);
+    return UCLSTM_OK;
+}
+
 bool wsrc_ok(const uclstm_src& s) {
     return s.ptr && s.C > 0 && (s.C % 8) == 0 && s.Hs > 0 && s.Ws > 0 && ((uintptr_t)s.ptr % 16) == 0;
 }
@@ -235,7 +489,7 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
     const uclstm_wgrad_desc& d = *dp;
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0) return UCLSTM_E_BADARG;
     if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
-    if (d.nsrc < 1 || d.nsrc > 2 || !d.dwp || d.N <= 0 || (d.N % 8) || d.splits < 1) return UCLSTM_E_BADARG;
+    if (d.nsrc < 1 || d.nsrc > 2 || !d.dwp || d.N <= 0 || (d.N % 8) || d.splits < 0) return UCLSTM_E_BADARG;
     if (d.nseg < 1 || d.nseg > 4) return UCLSTM_E_BADARG;
     bool plain = d.scale == 1;
     for (int s = 0; s < d.nsrc; ++s) {
@@ -256,19 +510,49 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
     dv.kseg1 = d.nsrc > 1 ? round_up32(d.src[1].C, 64) : 0;
     const int taps = d.ktap * d.ktap;
     if (d.Ktot != taps * (dv.kseg0 + dv.kseg1)) return UCLSTM_E_BADARG;
-    dv.n_kt = (d.Ktot + TC - 1) / TC;
-    dv.n_nt = (d.N + TN - 1) / TN;
     dv.M = (long)d.n_img * d.H * d.W;
     if (dv.M >= ((long)1 << 31) - 4096) return UCLSTM_E_BADARG;
-    long chunk = (dv.M + d.splits - 1) / d.splits;
-    chunk = (chunk + TP - 1) / TP * TP;
-    dv.chunk = chunk;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
     dv.dPerTap = make_fastdiv((uint32_t)(dv.kseg0 + dv.kseg1));
-    const int64_t nblk = (int64_t)dv.n_kt * dv.n_nt * d.splits;
-    if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
 
+    // fast path (buffer-addressed, division-free): see igemm_wgrad_p2_kernel
+    static const bool no_fast = [] { const char* e = getenv("UCLSTM_WGRAD_GENERIC"); return e && e[0] == '1'; }();
+    bool fast = plain && !no_fast && d.nseg == 1 && is_pow2(d.H) && is_pow2(d.W) && (dv.M % TP) == 0 &&
+                ((d.ktap == 3 && d.pad == 1) || (d.ktap == 1 && d.pad == 0));
+    P2 p2{};
+    if (fast) {
+        const int64_t lim = ((int64_t)1 << 31) - (1 << 22);
+        const int64_t yb = dv.M * d.seg[0].C * 2;
+        fast = yb < lim;
+        p2.ybytes = (uint32_t)yb;
+        for (int s = 0; s < d.nsrc && fast; ++s) {
+            const int64_t bias = (int64_t)(d.src[s].Ws + 1) * d.src[s].C * 2;
+            const int64_t xb = dv.M * d.src[s].C * 2 + bias;
+            fast = xb < lim;
+            p2.xbias[s] = (uint32_t)bias;
+            p2.xbytes[s] = (uint32_t)xb;
+        }
+        p2.lw = ilog2(d.W);
+        p2.lh = ilog2(d.H);
+    }
+    const int wn = (fast && d.N <= 64) ? 1 : 2;
+    const int tn = 64 * wn, tc = 256 / wn;
+    dv.n_kt = (d.Ktot + tc - 1) / tc;
+    dv.n_nt = (d.N + tn - 1) / tn;
+    uclstm_wgrad_desc dd = d;
+    if (dd.splits <= 0) dd.splits = auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP);
+    long chunk = (dv.M + dd.splits - 1) / dd.splits;
+    chunk = (chunk + TP - 1) / TP * TP;
+    dv.chunk = chunk;
+    const int64_t nblk = (int64_t)dv.n_kt * dv.n_nt * dd.splits;
+    if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+
+    if (fast) {
+        if (wn == 1) return d.nsrc == 1 ? launch_p2<1, 1>(dd, dv, p2, nblk, st) : launch_p2<1, 2>(dd, dv, p2, nblk, st);
+        return d.nsrc == 1 ? launch_p2<2, 1>(dd, dv, p2, nblk, st) : launch_p2<2, 2>(dd, dv, p2, nblk, st);
+    }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)igemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -276,8 +560,8 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
         attr_done = true;
     }
     if (plain)
-        UCLSTM_LAUNCH(igemm_wgrad_kernel<true>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, (hipStream_t)stream, d, dv);
+        UCLSTM_LAUNCH(igemm_wgrad_kernel<true>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, dd, dv);
     else
-        UCLSTM_LAUNCH(igemm_wgrad_kernel<false>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, (hipStream_t)stream, d, dv);
+        UCLSTM_LAUNCH(igemm_wgrad_kernel<false>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, dd, dv);
     return UCLSTM_OK;
 }

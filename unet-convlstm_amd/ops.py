@@ -376,12 +376,6 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
            f"M={B * H * W} N={d.N} K={d.Ktot}")
 
 
-def wgrad_splits(n_tiles: int, pixels: int) -> int:
-    """Pixel-range splits so that the grid reaches ~1024 blocks without dropping under 256 pixels per split."""
-    target = max(1, 1024 // max(n_tiles, 1))
-    return max(1, min(target, (pixels + 255) // 256))
-
-
 class ZeroArena:
     """Bump allocator over one f32 buffer that is zero-filled ONCE per training step.
 
@@ -443,12 +437,11 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
         _fill_seg(d.seg[i], *sg)
     d.dwp = dwp.data_ptr()
     taps = ktap * ktap
-    n_tiles = ((N + 127) // 128) * ((Ktot + 127) // 128)
-    d.splits = wgrad_splits(n_tiles, n_img * out_hw[0] * out_hw[1])
+    d.splits = 0              # 0 = the library picks the pixel-range splits for its tile shape (igemm_wgrad.hip auto_splits)
     d.accumulate = 1
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
     _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
+           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap}")
     return dwp
 
 
