@@ -12,10 +12,14 @@
 // Two block shapes: 128 panel rows x 128 pixels (waves 2x2) and, for C_out <= 64 layers,
 // 64 panel rows x 256 pixels (waves 1x4) so that no MFMA work is spent on absent channels.
 // LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte chunk (conflict-free
-// ds_read_b128, guide T2).  Operands go global->LDS directly (global_load_lds, 16 B/lane): per
-// staged row the tap-(0,0) offset and a 9-bit "tap inside the image" mask are computed once, so a
-// K-step costs ~1.5 VALU per MFMA instead of 4.4 (measured: the register-staged first version was
-// VALU-issue bound).  Two LDS stages, one barrier per K-step.
+// ds_read_b128, guide T2).  Operands go global->LDS directly through BUFFER descriptors
+// (buffer_load_dwordx4 ... lds, 16 B/lane).  Measured on gfx950 (tools/probes/): a lane whose
+// voffset + soffset is >= num_records writes 16 ZERO bytes into LDS, so padding costs no zero
+// page and no 64-bit select.  Per staged row the byte offset of tap (0,0) and a 9-bit "tap
+// outside the image" mask are computed once; a K-step then needs 2 VALU per activation row
+// (shift the mask bit of this tap into bit 31, OR it into the offset) and none for the weight
+// rows -- the (tap, channel) advance rides in the SGPR soffset.  (The register-staged first
+// version was VALU-issue bound at 4.4 VALU per MFMA.)  Two LDS stages, one barrier per K-step.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -24,8 +28,7 @@ namespace {
 
 constexpr int BK = 64;
 
-// 16-byte zero page: the source of every padded / out-of-tile operand row of the direct-to-LDS loads
-__device__ uint4 g_zero_page[2];
+constexpr uint32_t OOB = 0x80000000u;      // >= num_records of every descriptor (tensors are < 2 GiB here)
 
 struct Derived {
     int Mg;          // pixels per statistic group
@@ -37,6 +40,9 @@ struct Derived {
     int ksplit;      // K ranges (UCLSTM_EPI_ATOMIC only, else 1)
     int kper;        // K steps per range
     FastDiv dHW, dW; // pixel index -> (image, y, x)
+    uint32_t xbias[2];   // bytes the source descriptor starts before the tensor (tap (0,0) of a border pixel is "negative")
+    uint32_t xbytes[2];  // descriptor size: tensor bytes + bias
+    uint32_t wbytes;     // panel bytes
 };
 
 // Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64);
@@ -62,13 +68,14 @@ struct Shape {
 
 template <int EPI, int SHP, int NSRC>
 __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
     using SH = Shape<SHP>;
     constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR, NT = SH::NT, RS = SH::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / SH::WM;                    // wave position along panel rows
     const int wpx = wave - wc * SH::WM;              // wave position along pixels
     const int l15 = lane & 15;
@@ -90,18 +97,24 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     const int n0 = nt * TBN;
     const int HW = d.H * d.W;
 
-    // ---- operand staging: direct-to-LDS loads (global_load_lds, 16 B per lane, guide section 5) ----
-    // DMA instruction i of wave w fills LDS rows 32*i + 8*w + (lane>>3), 16-byte position lane&7 (1 KiB contiguous per
+    // ---- operand staging: direct-to-LDS buffer loads (16 B per lane, guide section 5) ----
+    // DMA instruction i of wave w fills LDS rows RS*i + 8*w + (lane>>3), 16-byte position lane&7 (1 KiB contiguous per
     // wave instruction).  The XOR swizzle sits on the SOURCE side: position p of row r receives channel chunk
     // p ^ (r&7) (rule 21: linear destination, swizzled source, swizzled read).  Rows whose tap falls outside the image,
-    // or beyond the tile's last pixel, read a 16-byte zero page instead.
+    // or beyond the tile's last pixel, get bit 31 set in their offset: out of range -> the DMA writes zeros.
     const int lrow0 = tid >> 3;                        // = 8*wave + (lane>>3)
     const int lchunk = (tid & 7) ^ (lrow0 & 7);        // channel chunk that belongs at this lane's LDS position
-    const uint64_t zero_addr = (uint64_t)(const void*)g_zero_page;
+    const __amdgpu_buffer_rsrc_t rsx0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[0].ptr - dv.xbias[0]), 0, dv.xbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx1 =
+        NSRC > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[1].ptr - dv.xbias[1]), 0, dv.xbytes[1], 0x00020000)
+                 : rsx0;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, dv.wbytes, 0x00020000);
 
-    // per staged row: element offset of tap (0,0) in each source, and a bit mask of the taps that land inside the image
-    int roff0[XR], roff1[XR];
-    uint32_t vm0[XR], vm1[XR];
+    // per staged row: byte offset of tap (0,0) in each source (descriptor-relative, never negative), and a bit mask of the
+    // taps that fall OUTSIDE the image (all ones for rows beyond the tile's last pixel)
+    uint32_t roff0[XR], roff1[XR];
+    uint32_t nv0[XR], nv1[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int r = lrow0 + RS * i;
@@ -112,34 +125,33 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
         const int y = (int)fdiv(rem, dv.dW);
         const int x = (int)rem - y * d.W;
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            int ro = 0;
+        for (int sidx = 0; sidx < NSRC; ++sidx) {
+            const uclstm_src S = d.src[sidx];
+            const int ys0 = y * d.scale - d.pad - S.offY;
+            const int xs0 = x * d.scale - d.pad - S.offX;
+            const uint32_t ro = (uint32_t)(2 * (((img * S.Hs + ys0) * S.Ws + xs0) * S.C + lchunk * 8) + (int)dv.xbias[sidx]);
             uint32_t mk = 0;
-            if (sidx < d.nsrc) {
-                const uclstm_src S = d.src[sidx];
-                const int ys0 = y * d.scale - d.pad - S.offY;
-                const int xs0 = x * d.scale - d.pad - S.offX;
-                ro = ((img * S.Hs + ys0) * S.Ws + xs0) * S.C + lchunk * 8;
-                if (rvalid) {
-                    // tap (j,k) is inside the image iff row j and column k are: 3 + 3 compares, no division
-                    uint32_t colm = 0;
+            if (rvalid) {
+                // tap (j,k) is inside the image iff row j and column k are: 3 + 3 compares, no division
+                uint32_t colm = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1u << k;
+                for (int k = 0; k < 3; ++k)
+                    if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1u << k;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (j < d.ktap && (unsigned)(ys0 + j) < (unsigned)S.Hs) mk |= colm << (j * d.ktap);
-                }
+                for (int j = 0; j < 3; ++j)
+                    if (j < d.ktap && (unsigned)(ys0 + j) < (unsigned)S.Hs) mk |= colm << (j * d.ktap);
             }
-            if (sidx == 0) { roff0[i] = ro; vm0[i] = mk; } else { roff1[i] = ro; vm1[i] = mk; }
+            // a lane whose channel chunk lies beyond a narrow source (C < 64) is never valid
+            if (lchunk * 8 >= S.C) mk = 0;
+            if (sidx == 0) { roff0[i] = ro; nv0[i] = ~mk; } else { roff1[i] = ro; nv1[i] = ~mk; }
         }
     }
-    // weight panel rows (clamped: rows >= N feed accumulators that are never stored)
-    uint64_t wrow[WR];
+    // weight panel rows: loop-invariant offsets, the K-step advances through soffset (rows >= N read zeros)
+    uint32_t wvoff[WR];
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-        const int nrow = min(n0 + lrow0 + RS * i, d.N - 1);
-        wrow[i] = (uint64_t)d.wp + ((uint64_t)nrow * (uint64_t)d.Ktot + (uint64_t)(lchunk * 8)) * 2u;
+        const int nrow = n0 + lrow0 + RS * i;
+        wvoff[i] = nrow < d.N ? (uint32_t)(2 * (nrow * d.Ktot + lchunk * 8)) : OOB;
     }
 
     f32x4 acc[4][4];
@@ -161,41 +173,37 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     }
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-    const int wrow_lds = wave * 8 * 128;               // this wave's first row in every 32-row group (bytes)
+    const int wrow_lds = wave * 8 * 128;               // this wave's first row in every RS-row group (bytes)
 
-    auto issue_src = [&](const int (&roff)[XR], const uint32_t (&vmask)[XR], const uclstm_src S, unsigned char* X) {
+    auto issue_src = [&](unsigned char* X) {
+        // NSRC == 2: the source of this K-step is wave-uniform (`s`), the per-row values are picked with scalar-condition
+        // selects (never by pointing a shared body at one of two register arrays: that sends the arrays to scratch)
+        const bool s1 = NSRC > 1 && s != 0;
+        const uclstm_src S = d.src[s1 ? 1 : 0];
+        const __amdgpu_buffer_rsrc_t rs = s1 ? rsx1 : rsx0;
         const int tdy = tap / d.ktap;
-        const int tapoff = (tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0;      // wave-uniform
-        // lane-level validity as one AND (kept branch-free: a select per load, never a second exec-masked DMA)
-        const uint32_t tbit = (c0 + lchunk * 8 < S.C) ? (1u << tap) : 0u;
-        const uint64_t base = (uint64_t)S.ptr;
+        const uint32_t tapoff = (uint32_t)(2 * ((tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0));      // wave-uniform -> soffset
+        const uint32_t sh = 31u - (uint32_t)tap;
+        // channels beyond a source whose width is not a multiple of 64: only the last K-step of its segment can see them
+        uint32_t cbad = 0;
+        if ((S.C & 63) && c0 + 64 > S.C) cbad = (c0 + lchunk * 8 >= S.C) ? OOB : 0u;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const uint64_t a_in = base + (uint64_t)((long)(roff[i] + tapoff) * 2);
-            const uint32_t hit = vmask[i] & tbit;
-            uint32_t lo = (uint32_t)a_in, hi = (uint32_t)(a_in >> 32);
-            asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %1, %4, %1, vcc"
-                         : "+v"(lo), "+v"(hi)
-                         : "v"(hit), "v"((uint32_t)zero_addr), "v"((uint32_t)(zero_addr >> 32))
-                         : "vcc");
-            const uint64_t addr = ((uint64_t)hi << 32) | lo;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)addr, (lds_ptr)(X + i * RS * 128 + wrow_lds), 16, 0, 0);
+            const uint32_t ro = (NSRC > 1) ? (s1 ? roff1[i] : roff0[i]) : roff0[i];
+            const uint32_t nv = (NSRC > 1) ? (s1 ? nv1[i] : nv0[i]) : nv0[i];
+            // bit `tap` of the outside-mask -> bit 31 of the offset: out of range, the DMA writes zeros
+            const uint32_t off = (((nv << sh) & OOB) | ro) | cbad;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(X + i * RS * 128 + wrow_lds), 16, off, tapoff, 0, 0);
         }
     };
     auto issue_loads = [&](int buf) {
         unsigned char* X = smem + buf * SH::STAGE;
         unsigned char* Wt = X + SH::XBYTES;
-        if constexpr (NSRC == 1) {
-            issue_src(roff0, vm0, d.src[0], X);      // straight-line: can be scheduled into the MFMA shadows
-        } else {
-            if (s == 0) issue_src(roff0, vm0, d.src[0], X);
-            else issue_src(roff1, vm1, d.src[1], X);
-        }
-        const uint64_t koff = (uint64_t)kstep * (BK * 2);
+        issue_src(X);
+        const uint32_t koff = (uint32_t)kstep * (BK * 2);
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow[i] + koff), (lds_ptr)(Wt + i * RS * 128 + wrow_lds), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(Wt + i * RS * 128 + wrow_lds), 16, wvoff[i], koff, 0, 0);
         // advance cursor
         ++kstep;
         c0 += BK;
@@ -435,6 +443,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
             }
         }
     }
+#endif
 }
 
 bool src_ok(const uclstm_src& s) {
@@ -491,9 +500,19 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
     for (int s = 0; s < d.nsrc; ++s)
         if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;
-    for (int s = 0; s < d.nsrc; ++s)       // the kernel addresses operand rows with 32-bit element offsets
-        if ((int64_t)d.n_img * d.src[s].Hs * d.src[s].Ws * d.src[s].C >= ((int64_t)1 << 31) - (1 << 20)) return UCLSTM_E_BADARG;
-    Derived dv;
+    Derived dv{};
+    const int64_t lim = ((int64_t)1 << 31) - (1 << 22);      // descriptors are addressed with bit 31 = "out of range"
+    for (int s = 0; s < d.nsrc; ++s) {
+        const uclstm_src& S = d.src[s];
+        const int64_t by = d.pad + S.offY, bx = d.pad + S.offX;
+        const int64_t bias = 2 * ((by > 0 ? by : 0) * S.Ws + (bx > 0 ? bx : 0) + 1) * S.C;
+        const int64_t bytes = (int64_t)d.n_img * S.Hs * S.Ws * S.C * 2 + bias;
+        if (bytes >= lim) return UCLSTM_E_BADARG;
+        dv.xbias[s] = (uint32_t)bias;
+        dv.xbytes[s] = (uint32_t)bytes;
+    }
+    if ((int64_t)d.N * d.Ktot * 2 >= lim) return UCLSTM_E_BADARG;
+    dv.wbytes = (uint32_t)((int64_t)d.N * d.Ktot * 2);
     dv.kseg0 = round_up32(d.src[0].C, BK);
     dv.kseg1 = d.nsrc > 1 ? round_up32(d.src[1].C, BK) : 0;
     const int taps = d.ktap * d.ktap;
