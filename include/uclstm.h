@@ -183,6 +183,11 @@ int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, c
                             const float* mean, const float* rstd, const float* sums, void* dz,
                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
 
+/* Parameter gradients of the BatchNorm (train/unet.py:70) from the sums of pass 1, summed over the groups in order:
+ * dbeta[c] = (accumulate ? dbeta[c] : 0) + sum_g sums[g][c][0],  dgamma likewise from sums[g][c][1],  c < C. */
+int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, int32_t Cp, int32_t C, float* dgamma, float* dbeta,
+                                  int32_t accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* MaxPool2d(2) (train/unet.py:81)                                                      */
 /* ------------------------------------------------------------------------------------ */

@@ -683,6 +683,28 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
     return UCLSTM_OK;
 }
 
+__global__ void bn_bwd_param_grads_kernel(const float* __restrict__ sums, int groups, int Cp, int C, float* __restrict__ dgamma,
+                                          float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const float2 v = *(const float2*)(sums + ((long)g * Cp + c) * 2);
+        s1 += v.x;
+        s2 += v.y;
+    }
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+}
+
+extern "C" int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, int32_t Cp, int32_t C, float* dgamma, float* dbeta,
+                                             int32_t accumulate, void* stream) {
+    if (!sums || !dgamma || !dbeta || groups <= 0 || Cp <= 0 || C <= 0 || C > Cp) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(bn_bwd_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, groups, Cp, C, dgamma,
+                  dbeta, accumulate);
+    return UCLSTM_OK;
+}
+
 extern "C" int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream) {
     if (!aligned16(a) || !aligned16(p) || n_img <= 0 || H < 2 || W < 2 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
     const int Ho = H / 2, Wo = W / 2;

@@ -305,6 +305,23 @@ def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[to
     return None
 
 
+def direct_grad(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """``param.grad`` when a backward kernel may accumulate into it directly (pre-attached contiguous f32 buffer, as
+    ``optim.FlatParams`` provides), else ``None``.  Saves autograd's tiny per-parameter accumulate kernels."""
+    if param is None or not ASYNC_WGRAD:
+        return None
+    g = param.grad
+    if g is None or g.dtype != F32 or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
+
+
+def grad_written(param: torch.Tensor) -> None:
+    """Tell data-parallel code that ``param.grad`` has been written outside autograd's accumulator."""
+    for hook in GRAD_SIDE_HOOKS:
+        hook(param)
+
+
 # ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
@@ -603,7 +620,7 @@ class ConvBNReLU(torch.autograd.Function):
             a = torch.empty_like(z)
             L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
                     "bn_apply_relu")
-            ctx.save_for_backward(x0, x1, weight, z, par, gamma)
+            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
         else:
             par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -611,13 +628,13 @@ class ConvBNReLU(torch.autograd.Function):
             a = out
             igemm_store(srcs, wp, (H, W), n_img, [(a, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp,
                         col_scale=par[0], col_shift=par[1], relu=True)
-            ctx.save_for_backward(x0, x1, weight, None, None, gamma)
+            ctx.save_for_backward(x0, x1, weight, None, None, gamma, beta, bias)
         ctx.cfg = (tuple(c_valid), tuple(off), groups, training, im2col, Co, Ci_total, bias is not None)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x0, x1, weight, z, par, gamma = ctx.saved_tensors
+        x0, x1, weight, z, par, gamma, beta, bias = ctx.saved_tensors
         c_valid, off, groups, training, im2col, Co, Ci_total, has_bias = ctx.cfg
         if not training:
             raise L.UclstmError("backward through eval-mode BatchNorm is not implemented (reference trains in train mode)")
@@ -625,17 +642,31 @@ class ConvBNReLU(torch.autograd.Function):
         n_img, H, W, Cop = z.shape
         dev = z.device
         pixels, ppg = n_img * H * W, (n_img // groups) * H * W
-        sums = torch.zeros((groups, Cop, 2), dtype=F32, device=dev)
+        sums = arena(dev).take((groups, Cop, 2), dev)         # zeroed once per step with the other accumulators
         L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), pixels, ppg, Cop,
                                            _stream()), "bn_bwd_reduce")
         dz = torch.empty_like(z)
         L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), _p(dz), pixels, ppg,
                                           Cop, _stream()), "bn_bwd_apply")
-        tot = sums.sum(dim=0)
-        dbeta = tot[:Co, 0].contiguous()
-        dgamma = tot[:Co, 1].contiguous()
         # conv bias feeds BatchNorm, which removes any per-channel constant: its gradient is analytically 0
-        dbias = torch.zeros((Co,), dtype=F32, device=dev) if has_bias else None
+        g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
+        if g_gamma is not None and g_beta is not None:
+            # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates)
+            L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
+            dgamma = dbeta = None
+            grad_written(gamma)
+            grad_written(beta)
+            dbias = None
+            if has_bias:
+                if direct_grad(bias) is not None:
+                    grad_written(bias)                          # += 0
+                else:
+                    dbias = torch.zeros((Co,), dtype=F32, device=dev)
+        else:
+            tot = sums.sum(dim=0)
+            dbeta = tot[:Co, 0].contiguous()
+            dgamma = tot[:Co, 1].contiguous()
+            dbias = torch.zeros((Co,), dtype=F32, device=dev) if has_bias else None
 
         dy_seg = [(dz, 0, Cop, 0, 1, 0, 0)]
         if im2col:
