@@ -187,6 +187,14 @@ def test_conv3x3_padded_second_source_and_groups_stats():
         torch.testing.assert_close(s[g, :, 1], (blk * blk).sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("pixels,Cp", [(1000, 8), (777, 1024), (300, 4096), (5000, 2056), (40960, 64), (7, 24)])
+def test_colsum(pixels, Cp):
+    torch.manual_seed(11)
+    a = bf(torch.randn(pixels, Cp))
+    got = ops.colsum(a.to(DEV).to(torch.bfloat16)).cpu()
+    torch.testing.assert_close(got, a.float().sum(0), rtol=1e-4, atol=2e-3 * pixels ** 0.5)
+
+
 # ---------------------------------------------------------------------------------------------
 # weight gradient (ds_read_b64_tr_b16 path)
 # ---------------------------------------------------------------------------------------------

@@ -583,36 +583,49 @@ __global__ void outconv_bwd_dw_kernel(const uint4* __restrict__ a, const float* 
     }
 }
 
+// Column sums of a [pixels][Cp] bf16 tensor (bias gradients).  grid.x = pixel ranges, grid.y = groups of NT 16-byte
+// column chunks; a thread owns one chunk column of `rows` interleaved pixel rows and keeps four loads in flight.
 __global__ void colsum_kernel(const uint4* __restrict__ a, float* __restrict__ out, int64_t pixels, ColGeom cg, int Cp,
                               int64_t pix_per_block) {
     extern __shared__ float red[];   // [rows][min(cpc,NT)*8]
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(pixels, p0 + pix_per_block);
-    for (int cbase = 0; cbase < cg.cpc; cbase += NT) {
-        const int cc = cbase + (cg.cpc >= NT ? threadIdx.x : threadIdx.x % cg.cpc);
-        const int prow = cg.cpc >= NT ? 0 : threadIdx.x / cg.cpc;
-        const bool act = (cg.cpc >= NT) ? (cc < cg.cpc) : ((int)threadIdx.x < cg.active);
-        const int width = min(cg.cpc, NT) * 8;
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (act) {
-            for (int64_t p = p0 + prow; p < p1; p += cg.rows) {
-                float v[8];
-                unpack8(a[p * cg.cpc + cc], v);
+    const int cbase = blockIdx.y * NT;
+    const int cc = cbase + (cg.cpc >= NT ? threadIdx.x : threadIdx.x % cg.cpc);
+    const int prow = cg.cpc >= NT ? 0 : threadIdx.x / cg.cpc;
+    const bool act = (cg.cpc >= NT) ? (cc < cg.cpc) : ((int)threadIdx.x < cg.active);
+    const int width = min(cg.cpc, NT) * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+        const int64_t st = cg.rows;
+        int64_t p = p0 + prow;
+        for (; p + 3 * st < p1; p += 4 * st) {
+            const uint4 q0 = a[p * cg.cpc + cc], q1 = a[(p + st) * cg.cpc + cc], q2 = a[(p + 2 * st) * cg.cpc + cc],
+                        q3 = a[(p + 3 * st) * cg.cpc + cc];
+            float v0[8], v1[8], v2[8], v3[8];
+            unpack8(q0, v0);
+            unpack8(q1, v1);
+            unpack8(q2, v2);
+            unpack8(q3, v3);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s[i] += v[i];
-            }
-            float* r = red + prow * width + (cc - cbase) * 8;
+            for (int i = 0; i < 8; ++i) s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+        }
+        for (; p < p1; p += st) {
+            float v[8];
+            unpack8(a[p * cg.cpc + cc], v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = s[i];
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < width; j += NT) {
-            float t = 0.f;
-            for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
-            const int ch = cbase * 8 + j;
-            if (ch < Cp) atomicAdd(out + ch, t);
-        }
-        __syncthreads();
+        float* r = red + prow * width + (cc - cbase) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = s[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < width; j += NT) {
+        float t = 0.f;
+        for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+        const int ch = cbase * 8 + j;
+        if (ch < Cp && (cg.cpc >= NT ? (cbase + j / 8) < cg.cpc : true)) atomicAdd(out + ch, t);
     }
 }
 
@@ -846,10 +859,14 @@ extern "C" int32_t uclstm_outconv_bwd(const void* a, const float* w, const float
 extern "C" int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int32_t Cp, void* stream) {
     if (!aligned16(a) || !out || pixels <= 0 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
     const ColGeom cg = col_geom(Cp);
-    int nb = (int)((pixels + 511) / 512);
-    if (nb > 1024) nb = 1024;
+    const int ncg = (cg.cpc + NT - 1) / NT;                    // column groups (grid.y)
+    // ~2048 blocks in all (8 per CU), but at least 16 pixels per thread row so that the atomic tail stays small
+    int64_t nb = 2048 / ncg;
+    const int64_t maxb = (pixels + 16 * cg.rows - 1) / (16 * cg.rows);
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
     const int64_t ppb = (pixels + nb - 1) / nb;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 8 * sizeof(float);
-    UCLSTM_LAUNCH(colsum_kernel, dim3(nb), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
+    UCLSTM_LAUNCH(colsum_kernel, dim3((unsigned)nb, (unsigned)ncg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
     return UCLSTM_OK;
 }

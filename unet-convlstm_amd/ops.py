@@ -259,6 +259,7 @@ def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> tor
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
 GRAD_SIDE_HOOKS: list = []
 _SIDE_STREAMS = {}
 _JOIN_PENDING = set()
@@ -308,7 +309,7 @@ def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[to
 def direct_grad(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """``param.grad`` when a backward kernel may accumulate into it directly (pre-attached contiguous f32 buffer, as
     ``optim.FlatParams`` provides), else ``None``.  Saves autograd's tiny per-parameter accumulate kernels."""
-    if param is None or not ASYNC_WGRAD:
+    if param is None or not DIRECT_GRADS:
         return None
     g = param.grad
     if g is None or g.dtype != F32 or not g.is_contiguous() or g.shape != param.shape:
