@@ -316,9 +316,9 @@ def test_convtranspose_fwd_bwd():
     check_f32(bg.grad.cpu(), br.grad, "convT db")
 
 
-def test_outconv_fwd_bwd():
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(3, 12, 2, 6, 7), (2, 64, 1, 16, 16), (3, 24, 1, 5, 9), (2, 200, 3, 8, 8)])
+def test_outconv_fwd_bwd(N, Ci, Co, H, W):
     torch.manual_seed(7)
-    N, Ci, Co, H, W = 3, 12, 2, 6, 7
     x = bf(torch.randn(N, Ci, H, W))
     w, b = torch.randn(Co, Ci, 1, 1) * 0.3, torch.randn(Co)
     go = torch.randn(N, Co, H, W)

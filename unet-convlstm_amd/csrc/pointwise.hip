@@ -520,6 +520,37 @@ __global__ void outconv_fwd_kernel(const uint4* __restrict__ a, const float* __r
     }
 }
 
+// Same result with LPP = cpc (a power of two <= 64) lanes per pixel: every lane loads ONE 16-byte chunk (a pixel row is one
+// coalesced run over its lanes), keeps its 8 weights in registers and the lanes of a pixel combine by xor-shuffles.
+template <int LPP>
+__global__ void outconv_fwd_lanes_kernel(const uint4* __restrict__ a, const float* __restrict__ w, const float* __restrict__ b,
+                                         float* __restrict__ y, int64_t pixels, FastDiv dHW, int C, int Co) {
+    const int HW = dHW.d;
+    const int cc = threadIdx.x % LPP;
+    const int slot = threadIdx.x / LPP;
+    constexpr int PPB = NT / LPP;
+    for (int co = 0; co < Co; ++co) {
+        float wr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wr[i] = (cc * 8 + i < C) ? w[co * C + cc * 8 + i] : 0.f;
+        const float bias = b ? b[co] : 0.f;
+        for (int64_t p = (int64_t)blockIdx.x * PPB + slot; p < pixels; p += (int64_t)gridDim.x * PPB) {
+            float v[8];
+            unpack8(a[p * LPP + cc], v);
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i] * wr[i];
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (cc == 0) {
+                const uint32_t img = fdiv((uint32_t)p, dHW);
+                const uint32_t pix = (uint32_t)p - img * HW;
+                y[((int64_t)img * Co + co) * HW + pix] = acc + bias;
+            }
+        }
+    }
+}
+
 __global__ void outconv_bwd_da_kernel(const float* __restrict__ w, const float* __restrict__ dy, uint4* __restrict__ da, int64_t chunks,
                                       FastDiv dcpc, FastDiv dHW, int C, int Co) {
     const int cpc = dcpc.d, HW = dHW.d;
@@ -827,8 +858,22 @@ extern "C" int32_t uclstm_outconv_fwd(const void* a, const float* w, const float
     if (!aligned16(a) || !w || !y || n_img <= 0 || HW <= 0 || Cp < C || (Cp % 8) || C <= 0 || Co <= 0) return UCLSTM_E_BADARG;
     const int64_t pixels = n_img * HW;
     if (pixels >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(outconv_fwd_kernel, dim3(ew_grid(pixels)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, w, b, y, pixels,
-                       make_fastdiv(HW), Cp / 8, C, Co);
+    const int cpc = Cp / 8;
+    const int grid = ew_grid(pixels * cpc);
+    const FastDiv dHW = make_fastdiv(HW);
+    hipStream_t st = (hipStream_t)stream;
+#define UCLSTM_OUTCONV_LANES(L_) \
+    UCLSTM_LAUNCH(outconv_fwd_lanes_kernel<L_>, dim3(grid), dim3(NT), 0, st, (const uint4*)a, w, b, y, pixels, dHW, C, Co)
+    switch (cpc) {
+        case 2: UCLSTM_OUTCONV_LANES(2); break;
+        case 4: UCLSTM_OUTCONV_LANES(4); break;
+        case 8: UCLSTM_OUTCONV_LANES(8); break;
+        case 16: UCLSTM_OUTCONV_LANES(16); break;
+        case 32: UCLSTM_OUTCONV_LANES(32); break;
+        default:
+            UCLSTM_LAUNCH(outconv_fwd_kernel, dim3(ew_grid(pixels)), dim3(NT), 0, st, (const uint4*)a, w, b, y, pixels, dHW, cpc, C, Co);
+    }
+#undef UCLSTM_OUTCONV_LANES
     return UCLSTM_OK;
 }
 
