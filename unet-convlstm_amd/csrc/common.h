@@ -56,6 +56,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
+// Grouped ("super-tile") order of a 2-D tile grid: groups of GROUP consecutive a-tiles; inside a group the a index runs
+// fastest, then b.  The ~64 blocks resident on one XCD (consecutive ids after xcd_remap) then form a GROUP x 64/GROUP
+// rectangle: every operand slab is shared by several resident blocks instead of a whole row or column of the grid
+// streaming through the XCD's 4 MiB L2.  Bijective for any (na, nb).
+__device__ __forceinline__ void grouped_tile(int id, int na, int nb, int group, int& a, int& b) {
+    const int per_group = group * nb;
+    const int g = id / per_group;
+    const int first = g * group;
+    const int gsz = min(na - first, group);
+    const int r = id - g * per_group;
+    b = r / gsz;
+    a = first + (r - b * gsz);
+}
+
 // Division of a 31-bit dividend by a runtime constant: q = umulhi(m, magic) >> shift (Granlund-Montgomery
 // round-up form; exact for every m < 2^31).  magic == 0 encodes d == 1.
 struct FastDiv {

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     const int lid0 = xcd_remap(blockIdx.x, per_split * dv.ksplit);
     const int ks = lid0 / per_split;                 // K range of this block (0 unless split-K)
     const int lid = lid0 - ks * per_split;
-    const int nt = lid / dv.n_mtiles;
-    const int mt = lid - nt * dv.n_mtiles;
+    int nt, mt;
+    grouped_tile(lid, dv.n_ntiles, dv.n_mtiles, 8, nt, mt);      // 8 panel-row tiles x 8 pixel tiles resident per XCD
     const int kstep_begin = ks * dv.kper;
     const int kstep_end = min(dv.ksteps, kstep_begin + dv.kper);
     const int g = mt / dv.tpg;
@@ -160,16 +160,20 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // K-step cursor of the NEXT load: (tap, source, channel offset) of linear step `kstep`
-    int kstep = kstep_begin;
-    int tap, s, c0;
+    // K-step cursor of the NEXT load.  The panel's K axis is (tap, source, channel); the loop walks it CHANNEL-CHUNK MAJOR,
+    // TAP MINOR: the taps of one 64-channel chunk are consecutive steps, so the nine shifted reads of the same activation
+    // cache lines come back-to-back and hit in L2.  (Tap-major order re-read every activation line once per tap from
+    // beyond L2: PMC FETCH_SIZE showed 9-14x the algorithmic bytes on the 3x3 layers, profiles/round1_notes.md.)
+    // Linear step j -> chunk = j / taps (source s, channel offset c0), tap = j % taps; panel column block = tap*spt + chunk.
+    const int ntaps = d.ktap * d.ktap;
+    const int spt = (dv.kseg0 + dv.kseg1) / BK;          // 64-channel chunks per tap (both sources)
+    const int s0steps = dv.kseg0 / BK;
+    int tap, s, c0, chunk;
     {
-        const int spt = (dv.kseg0 + dv.kseg1) / BK;      // steps per tap
-        tap = kstep / spt;
-        const int r = kstep - tap * spt;
-        const int s0steps = dv.kseg0 / BK;
-        s = r >= s0steps ? 1 : 0;
-        c0 = (s ? r - s0steps : r) * BK;
+        chunk = kstep_begin / ntaps;
+        tap = kstep_begin - chunk * ntaps;
+        s = (NSRC > 1 && chunk >= s0steps) ? 1 : 0;
+        c0 = (s ? chunk - s0steps : chunk) * BK;
     }
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -200,25 +204,20 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
         unsigned char* X = smem + buf * SH::STAGE;
         unsigned char* Wt = X + SH::XBYTES;
         issue_src(X);
-        const uint32_t koff = (uint32_t)kstep * (BK * 2);
+        const uint32_t koff = (uint32_t)(tap * spt + chunk) * (BK * 2);
 #pragma unroll
         for (int i = 0; i < WR; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(Wt + i * RS * 128 + wrow_lds), 16, wvoff[i], koff, 0, 0);
-        // advance cursor
-        ++kstep;
-        c0 += BK;
-        if constexpr (NSRC == 1) {
-            const bool wrap = c0 >= dv.kseg0;        // scalar selects, no branch
-            c0 = wrap ? 0 : c0;
-            tap += wrap ? 1 : 0;
-        } else {
-            if (c0 >= (s == 0 ? dv.kseg0 : dv.kseg1)) {
-                c0 = 0;
-                if (++s == d.nsrc) {
-                    s = 0;
-                    ++tap;
-                }
-            }
+        // advance cursor: next tap of this chunk, then the next chunk (scalar selects, no branch)
+        ++tap;
+        const bool wrap = tap >= ntaps;
+        tap = wrap ? 0 : tap;
+        chunk += wrap ? 1 : 0;
+        c0 += wrap ? BK : 0;
+        if constexpr (NSRC > 1) {
+            const bool next_src = wrap && s == 0 && chunk >= s0steps;
+            s = next_src ? 1 : s;
+            c0 = next_src ? 0 : c0;
         }
     };
     // One K-step.  Program order: fragments of the first 32-deep half, then (ISSUE) the address math + DMA of the NEXT

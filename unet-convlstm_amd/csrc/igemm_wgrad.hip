@@ -36,6 +36,7 @@ struct WDerived {
     int n_kt, n_nt;
     long M;              // total pixels
     long chunk;          // pixels per split (multiple of 64)
+    int kt_per_tap;      // K-column tiles per tap when a tap is a whole number of tiles, else 0 (no tap-minor order)
     FastDiv dHW, dW, dPerTap;
 };
 
@@ -293,8 +294,16 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
     const int lid = xcd_remap(blockIdx.x, per_split * d.splits);
     const int sp = lid / per_split;
     const int rr = lid - sp * per_split;
-    const int kt = rr / dv.n_nt;
-    const int nt = rr - kt * dv.n_nt;
+    // resident blocks of an XCD = 8 panel-row tiles x 8 K-column tiles; the K-column tiles are visited TAP-MINOR (the taps
+    // of one channel range are neighbours and read the same activation lines, shifted)
+    int nt, kts;
+    grouped_tile(rr, dv.n_nt, dv.n_kt, 8, nt, kts);
+    int kt = kts;
+    if (dv.kt_per_tap > 0) {
+        const int ntaps = d.ktap * d.ktap;
+        const int cg = kts / ntaps;
+        kt = (kts - cg * ntaps) * dv.kt_per_tap + cg;
+    }
     const int n0 = nt * SH::TN_;
     const int kbase = kt * SH::TC_;
 
@@ -540,6 +549,7 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
     const int tn = 64 * wn, tc = 256 / wn;
     dv.n_kt = (d.Ktot + tc - 1) / tc;
     dv.n_nt = (d.N + tn - 1) / tn;
+    dv.kt_per_tap = (fast && ((dv.kseg0 + dv.kseg1) % tc) == 0) ? (dv.kseg0 + dv.kseg1) / tc : 0;
     uclstm_wgrad_desc dd = d;
     if (dd.splits <= 0) dd.splits = auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP);
     long chunk = (dv.M + dd.splits - 1) / dd.splits;
