@@ -213,6 +213,14 @@ def test_colsum(pixels, Cp):
     (8, 136, 72, 72, 4, 4),
     (16, 32, 0, 200, 2, 4),
     (3, 16, 8, 16, 8, 16),
+    # C_out >= 256 takes the 256x256 / 8-phase kernel (igemm_wgrad_p3_kernel): one K-tile only, two K-tiles, a partial
+    # second row tile, two sources, long pixel range with splits
+    (4, 64, 0, 256, 4, 4),
+    (8, 256, 0, 256, 4, 4),
+    (1, 136, 0, 320, 32, 32),
+    (2, 64, 64, 256, 16, 16),
+    (2, 64, 0, 512, 64, 64),
+    (6, 72, 200, 264, 8, 8),
 ])
 def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
     torch.manual_seed(3)

@@ -453,6 +453,265 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves, "8-phase" schedule (guide section 5; tools/probes/gemm256_8phase.hip reaches 1.15-1.25 PFLOP/s
+// with this structure on a plain GEMM where the 128x128 two-barrier loop plateaus near 0.9).  Same operand handling as
+// the fast path above (planes of [64 pixels][64 columns], buffer-addressed zero-filling DMA, scalar-vs-constant tap
+// validity); what changes is the pipeline:
+//   * a K-tile (64 pixels) is staged as four HALF-tiles of two planes (16 KiB): dY-lo, X-lo, X-hi, dY-hi, in the order the
+//     phases consume them; every phase issues one half-tile six halves ahead (LEAD) and waits with a COUNTED vmcnt, so up
+//     to four half-tiles stay in flight across the raw s_barriers (never vmcnt(0) in the steady state);
+//   * a wave owns 128 x 64 of the tile as four 64 x 32 quadrants, one quadrant (16 MFMA) per phase; its rows/columns are
+//     interleaved over the halves so that each half is read in exactly one phase: dY-lo + X-lo in phase 0, X-hi in 1,
+//     dY-hi in 2, none in 3 -> a half is re-staged at least two phases after its last read (write-after-read safe with the
+//     stagger below);
+//   * waves 4-7 run one barrier behind waves 0-3 (they share the SIMDs pairwise): one group's MFMA section overlaps the
+//     other group's LDS reads + DMA issue.
+// One block per CU (128 KiB LDS).  Used when C_out >= 256; pixel splits keep the grid a multiple of the 256 CUs.
+constexpr int P3_HALF = 2 * PLANE;            // 16 KiB
+constexpr int P3_BUF = 4 * P3_HALF;           // 64 KiB
+constexpr int P3_SMEM = 2 * P3_BUF;           // 128 KiB
+constexpr int P3_LEAD = 6;
+
+template <int NSRC>
+__global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgrad_desc d, const WDerived dv, const P2 p2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;     // along panel rows (also the stagger group)
+    const int wc = wave & 3;      // along K columns
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+
+    const int per_split = dv.n_kt * dv.n_nt;
+    const int lid = xcd_remap(blockIdx.x, per_split * d.splits);
+    const int sp = lid / per_split;
+    const int rr = lid - sp * per_split;
+    int nt, kts;
+    grouped_tile(rr, dv.n_nt, dv.n_kt, 4, nt, kts);
+    int kt = kts;
+    if (dv.kt_per_tap > 0) {
+        const int ntaps = d.ktap * d.ktap;
+        const int cg = kts / ntaps;
+        kt = (kts - cg * ntaps) * dv.kt_per_tap + cg;
+    }
+    const int n0 = nt * 256;
+    const int kbase = kt * 256;
+
+    const long m_begin = (long)sp * dv.chunk;
+    const long m_end = min(dv.M, m_begin + dv.chunk);
+    const int KT = m_begin < dv.M ? (int)((m_end - m_begin) / TP) : 0;      // block-uniform; 0: nothing to do (but every
+    if (KT == 0) return;                                                      // wave of the block leaves together)
+    const int total_halves = 4 * KT;
+
+    const uclstm_seg G = d.seg[0];
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)G.ptr, 0, p2.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[0].ptr - p2.xbias[0]), 0, p2.xbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx1 =
+        NSRC > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)d.src[1].ptr - p2.xbias[1]), 0, p2.xbytes[1], 0x00020000)
+                 : rsx0;
+
+    // ---- staging role: DMA instruction i of a half fills rows 8*wave + (lane>>3) of its plane i ----
+    const int lrow = lane >> 3;
+    const int cp = lane & 7;
+    const int sc = 2 * ((cp >> 1) ^ ((lrow >> 1) & 3)) + (cp & 1);      // source 16-byte chunk stored at this position
+    const int r = 8 * wave + lrow;                                       // pixel row of the stage
+    const int Wm = d.W - 1, Hm = d.H - 1;
+    const int kseg = dv.kseg0 + dv.kseg1;
+    uint32_t yvoff[4], xvoff[4], kxj[4], kyj[4];
+    int xsrc[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+        const int ny = n0 + pl * 64 + sc * 8;
+        const bool yok = ny < d.N && ny >= G.n_begin && ny < G.n_end;
+        yvoff[pl] = yok ? (uint32_t)(2 * (r * G.C + G.c_off + (ny - G.n_begin))) : OOB;
+        const int k0 = kbase + pl * 64;
+        const int xtap = (int)fdiv((uint32_t)k0, dv.dPerTap);
+        const int kr = k0 - xtap * kseg;
+        const int xs_ = (NSRC > 1 && kr >= dv.kseg0) ? 1 : 0;
+        const int xc = (xs_ ? kr - dv.kseg0 : kr) + sc * 8;
+        const uclstm_src S = d.src[xs_];
+        const bool xok = k0 < d.Ktot && xc < S.C;
+        const int tdy = xtap / d.ktap;
+        const int ddy = tdy - d.pad;
+        const int ddx = (xtap - tdy * d.ktap) - d.pad;
+        const int badx = ddx < 0 ? 0 : (ddx > 0 ? Wm : -1);
+        const int bady = ddy < 0 ? 0 : (ddy > 0 ? Hm : -1);
+        xsrc[pl] = xs_;
+        xvoff[pl] = xok ? (uint32_t)(2 * (r * S.C + (ddy * S.Ws + ddx) * S.C + xc) + (int)p2.xbias[xs_]) : OOB;
+        if (badx < 0) kxj[pl] = 0xffffffffu;
+        else if (d.W >= 64) kxj[pl] = (uint32_t)(badx - r);
+        else kxj[pl] = ((r & Wm) == badx) ? 0u : 0xffffffffu;
+        kyj[pl] = bady < 0 ? 0xffffffffu : (uint32_t)((bady - (r >> p2.lw)) & Hm);
+    }
+    const uint32_t ystep = (uint32_t)(2 * G.C), x0step = (uint32_t)(2 * d.src[0].C), x1step = (uint32_t)(2 * d.src[NSRC - 1].C);
+    const uint32_t mb0 = (uint32_t)m_begin;
+
+    // half-tile `slot` of K-tile `kt_`: 0 dY planes 0-1, 1 X planes 0-1, 2 X planes 2-3, 3 dY planes 2-3
+    auto issue_half = [&](int kt_, int slot) {
+        unsigned char* dst = smem + (kt_ & 1) * P3_BUF + slot * P3_HALF + wave * 1024;
+        const uint32_t mb = mb0 + (uint32_t)kt_ * TP;
+        if (slot == 0 || slot == 3) {
+            const uint32_t ysoff = mb * ystep;
+            const int p0 = slot == 0 ? 0 : 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (lds_ptr)(dst + i * PLANE), 16, slot == 0 ? yvoff[i] : yvoff[2 + i], ysoff, 0, 0);
+            (void)p0;
+        } else {
+            const uint32_t sy = (mb >> p2.lw) & (uint32_t)Hm;
+            const uint32_t sx = mb & (uint32_t)Wm;
+            const uint32_t x0soff = mb * x0step, x1soff = mb * x1step;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = (slot == 1 ? 0 : 2) + i;
+                const bool ok = (sx != kxj[pl]) & (sy != kyj[pl]);
+                const uint32_t off = ok ? xvoff[pl] : OOB;
+                if (NSRC == 1 || xsrc[pl] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx0, (lds_ptr)(dst + i * PLANE), 16, off, x0soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx1, (lds_ptr)(dst + i * PLANE), 16, off, x1soff, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposing fragment reads: offsets inside a plane (granule g of pixel row r at g ^ ((r>>1)&3))
+    const int trow = 4 * lq + (l15 >> 2);
+    const int tsw = (trow >> 1) & 3;
+    int goffA[4], goffB[2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) goffA[a] = wr * PLANE + trow * 128 + ((a ^ tsw) << 5) + (l15 & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) goffB[j] = (wc >> 1) * PLANE + trow * 128 + ((((wc & 1) * 2 + j) ^ tsw) << 5) + (l15 & 3) * 8;
+
+    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
+    // prologue: six half-tiles in flight, the first two (dY-lo, X-lo of K-tile 0) landed before the first phase
+#pragma unroll
+    for (int q = 0; q < P3_LEAD; ++q)
+        if (q < total_halves) issue_half(q >> 2, q & 3);
+    if (total_halves >= P3_LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: group 1 runs one barrier behind
+    __builtin_amdgcn_s_barrier();
+
+    int g = 0;
+    for (int ktile = 0; ktile < KT; ++ktile) {
+        const unsigned char* base = smem + (ktile & 1) * P3_BUF;
+#pragma unroll
+        for (int p = 0; p < 4; ++p, ++g) {
+            if (p == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) b0f[j][ks] = tr_frag128(base + 1 * P3_HALF + ks * 32 * 128 + goffB[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = tr_frag128(base + 0 * P3_HALF + ks * 32 * 128 + goffA[i]);
+            } else if (p == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) b1f[j][ks] = tr_frag128(base + 2 * P3_HALF + ks * 32 * 128 + goffB[j]);
+            } else if (p == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = tr_frag128(base + 3 * P3_HALF + ks * 32 * 128 + goffA[i]);
+            }
+            if (g + P3_LEAD < total_halves) {
+                issue_half(ktile + ((p + P3_LEAD) >> 2), (p + P3_LEAD) & 3);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            {
+                const int mh = (p >= 2) ? 1 : 0;
+                const int nh = (p == 1 || p == 2) ? 1 : 0;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const bf16x8 bb = nh ? b1f[j][ks] : b0f[j][ks];
+                            acc[mh][i][nh][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bb, acc[mh][i][nh][j], 0, 0, 0);
+                        }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // balance the stagger: both groups are past their last LDS read
+    __syncthreads();
+
+    // ---- accumulate into dWp: four passes of 64 panel rows, LDS-staged so that a wave instruction adds 64 consecutive floats
+    constexpr int AP = 256 + 4;
+    float* At = (float*)smem;                // [64 panel rows][AP] = 65 KiB
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int mh = pass >> 1, pwr = pass & 1;
+        if (wr == pwr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            At[(i * 16 + lq * 4 + q) * AP + nh * 128 + wc * 32 + j * 16 + l15] = mh ? acc[1][i][nh][j][q] : acc[0][i][nh][j][q];
+        }
+        __syncthreads();
+        const int col = tid & 255;
+        const int k = kbase + col;
+        if (k < d.Ktot) {
+            for (int pr = tid >> 8; pr < 64; pr += 2) {
+                const int n = n0 + mh * 128 + pwr * 64 + pr;
+                if (n < d.N)
+                    __hip_atomic_fetch_add(d.dwp + (long)n * d.Ktot + k, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+// splits for the one-block-per-CU kernel: whole rounds of 256 blocks, ~12 stages' worth of fixed cost per block
+int auto_splits256(int64_t tiles, int64_t stages) {
+    int best = 1;
+    int64_t best_cost = -1;
+    const int64_t smax = stages / 8 > 1 ? stages / 8 : 1;
+    for (int64_t s = 1; s <= smax && tiles * s <= 8192; ++s) {
+        const int64_t per = (stages + s - 1) / s;
+        const int64_t used = (stages + per - 1) / per;
+        const int64_t rounds = (tiles * used + 255) / 256;
+        const int64_t cost = rounds * (per + 12);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = (int)s;
+        }
+    }
+    return best;
+}
+
 // Pixel-range splits: minimise (rounds of the 512 resident blocks) x (stages per block + fixed cost of a block's
 // prologue and its 64-KiB atomic epilogue, ~8 stages' worth).
 int auto_splits(int64_t tiles, int64_t stages) {
@@ -545,13 +804,17 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
         p2.lw = ilog2(d.W);
         p2.lh = ilog2(d.H);
     }
+    static const bool no_p3 = [] { const char* e = getenv("UCLSTM_WGRAD_NO256"); return e && e[0] == '1'; }();
+    const bool big = fast && !no_p3 && d.N >= 256;              // 256 x 256 tile, 8-phase pipeline
     const int wn = (fast && d.N <= 64) ? 1 : 2;
-    const int tn = 64 * wn, tc = 256 / wn;
+    const int tn = big ? 256 : 64 * wn, tc = big ? 256 : 256 / wn;
     dv.n_kt = (d.Ktot + tc - 1) / tc;
     dv.n_nt = (d.N + tn - 1) / tn;
     dv.kt_per_tap = (fast && ((dv.kseg0 + dv.kseg1) % tc) == 0) ? (dv.kseg0 + dv.kseg1) / tc : 0;
     uclstm_wgrad_desc dd = d;
-    if (dd.splits <= 0) dd.splits = auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP);
+    if (dd.splits <= 0)
+        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP)
+                        : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP);
     long chunk = (dv.M + dd.splits - 1) / dd.splits;
     chunk = (chunk + TP - 1) / TP * TP;
     dv.chunk = chunk;
@@ -559,6 +822,17 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
     if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
 
+    if (big) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            attr3 = true;
+        }
+        if (d.nsrc == 1) UCLSTM_LAUNCH(igemm_wgrad_p3_kernel<1>, dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+        else UCLSTM_LAUNCH(igemm_wgrad_p3_kernel<2>, dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+        return UCLSTM_OK;
+    }
     if (fast) {
         if (wn == 1) return d.nsrc == 1 ? launch_p2<1, 1>(dd, dv, p2, nblk, st) : launch_p2<1, 2>(dd, dv, p2, nblk, st);
         return d.nsrc == 1 ? launch_p2<2, 1>(dd, dv, p2, nblk, st) : launch_p2<2, 2>(dd, dv, p2, nblk, st);
