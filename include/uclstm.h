@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 1
+#define UCLSTM_ABI_VERSION 2
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -93,10 +93,14 @@ typedef struct {
     float* c_out;                /* f32 [pixels][Hd_p] */
     void* h_out;                 /* bf16 [pixels][Hd_p] */
     void* gates_out;             /* bf16 [pixels][4][Hd_p] post-activation i,f,g,o or NULL (inference) */
-    /* UCLSTM_EPI_ATOMIC: acc_out[pixel*acc_ld + n] += tile (no bias); the caller zeroes / pre-loads acc_out */
+    /* UCLSTM_EPI_ATOMIC: acc_out[pixel*acc_ld + n] += tile (no bias); the caller zeroes / pre-loads acc_out.
+     * acc_slab > 0: no atomics -- K range r STORES its tile into acc_out + r*acc_slab (floats); every element of each
+     * of the uclstm_igemm_ksplit_used() slabs is written exactly once and the consumer adds the slabs
+     * (global f32 atomics run at ~1.3 TB/s on MI355X, plain stores at ~6 TB/s). */
     float* acc_out;
     int32_t acc_ld;
     int32_t ksplit;              /* requested K ranges (>= 1) */
+    int64_t acc_slab;
 } uclstm_igemm_desc;
 
 /* Rows of `stats` per group for a descriptor with N panel rows: ceil((n_img/groups)*H*W / tile_pixels),
@@ -109,6 +113,8 @@ int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_
  *   gradient (:90,:94), and with UCLSTM_EPI_LSTM the whole ConvLSTMCell.forward (:21-36:
  *   cat + conv + chunk + sigmoid/tanh + cell update in one kernel). */
 int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* d, void* stream);
+/* Number of non-empty K ranges uclstm_igemm_fwd will use for (Ktot, requested ksplit): the slab count of acc_slab mode. */
+int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit);
 
 /* Weight gradient  dWp[n][k] (+)= sum_pixels dY[pixel][n] * A[pixel][k]  (f32 [N][Ktot], same
  * K order as the forward panel).  dY is read through seg[] (nseg >= 1); `splits` pixel ranges
@@ -201,11 +207,14 @@ int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_i
 /* dh = dh_a (+ dh_b); dc = dc_io + dh*o*(1-tanh(c)^2); dgates = pre-activation gradients
  * bf16 [pixels][4][Hd_p] (i,f,g,o); dc_io <- dc*f (gradient w.r.t. c_prev). */
 int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new,
-                                  const void* dh_a, const void* dh_b, int32_t dh_b_is_f32, float* dc_io, int32_t dc_is_zero,
-                                  void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
+                                  const void* dh_a, const void* dh_b, int32_t dh_b_is_f32 /* 0 bf16, 1 f32, 2 f32 and cleared after reading */,
+                                  int32_t dh_b_nslab /* f32 only: dh_b is the sum of this many slabs */, int64_t dh_b_slab /* floats between slabs */,
+                                  float* dc_io, int32_t dc_is_zero, void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
 /* Gate nonlinearities + cell update (train/unet.py:29-35) for the split-K form of the cell: `pre` is the f32
  * pre-activation [pixels][N] in the gate-interleaved panel-row order (N = 64*ceil(Hd/16)), bias in the same order. */
-int32_t uclstm_lstm_fwd_pointwise(float* pre /* consumed: read, then cleared to 0 for the next step's accumulation */, const float* bias, const float* c_prev, float* c_out, void* h_out,
+int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab /* pre-activation = sum of nslab slabs */, int64_t slab /* floats between slabs */,
+                                  int32_t clear /* != 0: zero what was read (atomic accumulator reused by the next step) */,
+                                  const float* bias, const float* c_prev, float* c_out, void* h_out,
                                   void* gates_out, int64_t pixels, int32_t Hd_p, void* stream);
 
 /* ------------------------------------------------------------------------------------ */

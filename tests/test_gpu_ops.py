@@ -396,11 +396,22 @@ def test_lstm_fused_kernel_and_split_k_form_agree():
     pre = torch.zeros(B * H * W, wp.shape[0], device=DEV)
     ops.igemm_atomic([ops.SrcView(x), ops.SrcView(h)], wp, (H, W), B, pre, 5, ktap=3, pad=1)
     L = U._lib
-    L.check(L.lib.uclstm_lstm_fwd_pointwise(pre.data_ptr(), bp.data_ptr(), c.data_ptr(), c2.data_ptr(), h2.data_ptr(), g2.data_ptr(),
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(pre.data_ptr(), 1, 0, 1, bp.data_ptr(), c.data_ptr(), c2.data_ptr(), h2.data_ptr(), g2.data_ptr(),
                                             B * H * W, Hdp, None), "lstm_fwd_pointwise")
+    assert float(pre.abs().max()) == 0.0, "clear != 0 must leave a zero accumulator"
     check_f32(c2.cpu(), c1.cpu(), "split-K cell c vs fused", l2=1e-5)
     check_bf16(h2.float().cpu(), h1.float().cpu(), "split-K cell h vs fused", l2=1e-3, mx=8e-3)
     check_bf16(g2.float().cpu(), g1.float().cpu(), "split-K cell gates vs fused", l2=1e-3, mx=8e-3)
+    # slab form: every K range stores into its own slab (no atomics, no zero-fill), the point-wise kernel adds them
+    c3, h3, g3 = outs()
+    nsl = ops.ksplit_used(wp.shape[1], 5)
+    slabs = torch.full((nsl, B * H * W, wp.shape[0]), float("nan"), device=DEV)
+    ops.igemm_atomic([ops.SrcView(x), ops.SrcView(h)], wp, (H, W), B, slabs, 5, ktap=3, pad=1, slabs=True)
+    assert bool(torch.isfinite(slabs).all()), "every slab element must be written"
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(slabs.data_ptr(), nsl, slabs.stride(0), 0, bp.data_ptr(), c.data_ptr(), c3.data_ptr(),
+                                            h3.data_ptr(), g3.data_ptr(), B * H * W, Hdp, None), "lstm_fwd_pointwise")
+    check_f32(c3.cpu(), c1.cpu(), "slab split-K cell c vs fused", l2=1e-5)
+    check_bf16(h3.float().cpu(), h1.float().cpu(), "slab split-K cell h vs fused", l2=1e-3, mx=8e-3)
     # and against the oracle on the same rounded operands
     xr, hr = from_nhwc(x, Cx), from_nhwc(h, Hd)
     cr = c[..., :Hd].cpu().permute(0, 3, 1, 2)

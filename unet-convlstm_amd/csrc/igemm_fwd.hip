@@ -367,9 +367,11 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
             if (n < d.N) {
                 for (int pr = tid / TBN; pr < 64; pr += RPI) {
                     const int prow = blk * 64 + pr;
-                    if (prow < rows_valid)
-                        __hip_atomic_fetch_add(d.acc_out + (m0 + prow) * (long)d.acc_ld + n, At[pr * AP + col], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                    if (prow < rows_valid) {
+                        float* dst = d.acc_out + (long)ks * d.acc_slab + (m0 + prow) * (long)d.acc_ld + n;
+                        if (d.acc_slab > 0) *dst = At[pr * AP + col];          // this K range's own slab: plain 256-byte runs
+                        else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             __syncthreads();
@@ -491,6 +493,13 @@ extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_
     return (int32_t)((mg + bm - 1) / bm);
 }
 
+extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit) {
+    if (Ktot <= 0 || (Ktot % BK) || ksplit < 1) return UCLSTM_E_BADARG;
+    const int ksteps = Ktot / BK;
+    const int kper = (ksteps + ksplit - 1) / ksplit;
+    return (ksteps + kper - 1) / kper;
+}
+
 extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (!dp) return UCLSTM_E_BADARG;
     const uclstm_igemm_desc& d = *dp;
@@ -530,7 +539,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     dv.ksplit = 1;
     dv.kper = dv.ksteps;
     if (d.epi == UCLSTM_EPI_ATOMIC) {
-        if (!d.acc_out || d.acc_ld < d.N || d.ksplit < 1) return UCLSTM_E_BADARG;
+        if (!d.acc_out || d.acc_ld < d.N || d.ksplit < 1 || d.acc_slab < 0) return UCLSTM_E_BADARG;
+        if (d.acc_slab > 0 && d.acc_slab < mg * d.groups * (int64_t)d.acc_ld) return UCLSTM_E_BADARG;
         dv.kper = (dv.ksteps + d.ksplit - 1) / d.ksplit;
         dv.ksplit = (dv.ksteps + dv.kper - 1) / dv.kper;      // every K range is non-empty
     }

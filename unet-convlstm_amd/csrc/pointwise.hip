@@ -294,9 +294,9 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // ---------------------------------------------------------------------------------------------
 // Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
 // (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
-__global__ void lstm_fwd_pw_kernel(float* pre, const float* __restrict__ bias, const float* __restrict__ c_prev,
-                                   float* __restrict__ c_out, bf16* __restrict__ h_out, bf16* __restrict__ gates_out, int64_t items,
-                                   FastDiv dq, int Hd_p, int N) {
+__global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ bias,
+                                   const float* __restrict__ c_prev, float* __restrict__ c_out, bf16* __restrict__ h_out,
+                                   bf16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
         const uint32_t pix = fdiv((uint32_t)idx, dq);
         const int hc = ((uint32_t)idx - pix * dq.d) * 4;                 // first hidden channel of the quad
@@ -305,9 +305,13 @@ __global__ void lstm_fwd_pw_kernel(float* pre, const float* __restrict__ bias, c
         float g4[4][4];
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
-            const float4 v = *(const float4*)(pp + gate * 16);
-            // consume-and-clear: the split-K GEMM of the next timestep accumulates into this buffer again
-            *(float4*)(const_cast<float*>(pp) + gate * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = *(const float4*)(pp + gate * 16);
+            for (int sl = 1; sl < nslab; ++sl) {          // split-K slabs (plain stores of the K ranges)
+                const float4 u = *(const float4*)(pp + sl * slab + gate * 16);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            // consume-and-clear: an atomic split-K GEMM of the next timestep accumulates into this buffer again
+            if (clear) *(float4*)(const_cast<float*>(pp) + gate * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 b = bias ? *(const float4*)(bias + nb + gate * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             g4[gate][0] = v.x + b.x; g4[gate][1] = v.y + b.y; g4[gate][2] = v.z + b.z; g4[gate][3] = v.w + b.w;
         }
@@ -337,7 +341,7 @@ __global__ void lstm_fwd_pw_kernel(float* pre, const float* __restrict__ bias, c
 }
 
 __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
-                                   const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32,
+                                   const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32, int dh_b_nslab, int64_t dh_b_slab,
                                    float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
     const int cpc = dcpc.d;
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
@@ -363,6 +367,12 @@ __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float*
             if (dh_b_is_f32) {
                 float* p32 = (float*)const_cast<void*>(dh_b) + idx * 8;
                 load8f(p32, t);
+                for (int sl = 1; sl < dh_b_nslab; ++sl) {      // split-K slabs
+                    float u[8];
+                    load8f(p32 + sl * dh_b_slab, u);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[i] += u[i];
+                }
                 if (dh_b_is_f32 == 2) {     // consume-and-clear (split-K accumulator reused two timesteps later)
                     const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     store8f(p32, z8);
@@ -770,28 +780,31 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, 
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, const float* bias, const float* c_prev, float* c_out, void* h_out,
+extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t slab, int32_t clear, const float* bias, const float* c_prev, float* c_out, void* h_out,
                                              void* gates_out, int64_t pixels, int32_t Hd_p, void* stream) {
     if (!aligned16(pre) || !aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
     if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return UCLSTM_E_BADARG;
     const int64_t items = pixels * (Hd_p / 4);
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     const int N = 64 * ((Hd_p + 15) / 16);
-    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, bias, c_prev, c_out, (bf16*)h_out,
+    if (nslab < 1 || (nslab > 1 && (slab <= 0 || (slab % 4)))) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, bias, c_prev, c_out, (bf16*)h_out,
                   (bf16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new, const void* dh_a,
-                                             const void* dh_b, int32_t dh_b_is_f32, float* dc_io, int32_t dc_is_zero, void* dgates,
-                                             int64_t pixels, int32_t Hd_p, void* stream) {
+                                             const void* dh_b, int32_t dh_b_is_f32, int32_t dh_b_nslab, int64_t dh_b_slab, float* dc_io,
+                                             int32_t dc_is_zero, void* dgates, int64_t pixels, int32_t Hd_p, void* stream) {
+    if (dh_b && dh_b_is_f32 && (dh_b_nslab < 1 || (dh_b_nslab > 1 && (dh_b_slab <= 0 || (dh_b_slab % 4))))) return UCLSTM_E_BADARG;
     if (!aligned16(gates) || !aligned16(c_new) || !aligned16(dc_io) || !aligned16(dgates) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8))
         return UCLSTM_E_BADARG;
     if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Hd_p / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
-                       (const uint4*)dh_a, dh_b, dh_b_is_f32, dc_io, dc_is_zero, (uint4*)dgates, chunks, make_fastdiv(Hd_p / 8));
+                       (const uint4*)dh_a, dh_b, dh_b_is_f32, dh_b_nslab, dh_b_slab, dc_io, dc_is_zero, (uint4*)dgates, chunks,
+                       make_fastdiv(Hd_p / 8));
     return UCLSTM_OK;
 }
 

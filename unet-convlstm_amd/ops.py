@@ -357,9 +357,19 @@ def split_k_factor(pixels: int, N: int, ksteps: int, min_blocks: int = 384, targ
     return max(1, min((target + tiles - 1) // tiles, ksteps // 8))
 
 
+def ksplit_used(Ktot: int, ksplit: int) -> int:
+    """K ranges the library really uses for a requested split (every range non-empty) = slab count of ``slabs=True``."""
+    n = int(L.lib.uclstm_igemm_ksplit_used(Ktot, ksplit))
+    if n < 1:
+        raise L.UclstmError(f"igemm_ksplit_used({Ktot}, {ksplit}): bad argument")
+    return n
+
+
 def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
-                 ktap: int, scale: int = 1, pad: int = 0) -> None:
-    """acc_out[pixel, n] += conv(srcs)[pixel, n] as `ksplit` K ranges with f32 atomics (acc_out f32 [pixels, ld>=N])."""
+                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False) -> None:
+    """Split-K convolution as `ksplit` K ranges.  ``slabs=False``: acc_out[pixel, n] += ... with f32 atomics
+    (acc_out f32 [pixels, ld>=N], zeroed by the caller).  ``slabs=True``: acc_out is [ksplit_used, pixels, ld]; range r
+    stores into acc_out[r] and the consumer adds the slabs (plain stores run ~4.6x faster than float atomics)."""
     _dev(acc_out, F32, "acc_out")
     d = L.IgemmDesc()
     d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], 1
@@ -369,6 +379,9 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
     d.wp, d.N, d.Ktot = wp.data_ptr(), wp.shape[0], wp.shape[1]
     d.relu, d.epi, d.nseg = 0, L.EPI_ATOMIC, 0
     d.acc_out, d.acc_ld, d.ksplit = acc_out.data_ptr(), acc_out.shape[-1], ksplit
+    d.acc_slab = acc_out.stride(0) if slabs else 0
+    if slabs and (acc_out.dim() != 3 or acc_out.shape[0] != ksplit_used(d.Ktot, ksplit) or not acc_out.is_contiguous()):
+        raise L.UclstmError("igemm_atomic(slabs=True): acc_out must be a contiguous [ksplit_used, pixels, ld] tensor")
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
     _timed("igemm_fwd_atomic", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
@@ -827,15 +840,16 @@ class ConvLSTMSeq(torch.autograd.Function):
         # gate convolution as split-K partial tiles accumulated in f32 and apply the cell update in a point-wise kernel;
         # otherwise one fused kernel per step (gates never leave registers).
         ksplit = split_k_factor(B * H * W, wp.shape[0], wp.shape[1] // 64)
-        # zeroed once: the point-wise kernel clears what it consumes, so every step finds a zero accumulator
-        pre = torch.zeros((B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
+        # one f32 slab per K range (plain stores; the point-wise kernel adds them): no atomics, nothing to zero
+        nsl = ksplit_used(wp.shape[1], ksplit) if ksplit > 1 else 0
+        pre = torch.empty((nsl, B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
             c_prev = c_hist[t] if (c0 is not None or t > 0) else None
             g_t = gates[t] if need_grad else None
             if ksplit > 1:
-                igemm_atomic([SrcView(x_all[t]), SrcView(h_hist[t])], wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2)
-                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), _p(bp), _p(c_prev), _p(c_hist[t + 1]), _p(h_hist[t + 1]), _p(g_t),
-                                                        B * H * W, Hdp, _stream()), "lstm_fwd_pointwise")
+                igemm_atomic([SrcView(x_all[t]), SrcView(h_hist[t])], wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2, slabs=True)
+                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(bp), _p(c_prev), _p(c_hist[t + 1]),
+                                                        _p(h_hist[t + 1]), _p(g_t), B * H * W, Hdp, _stream()), "lstm_fwd_pointwise")
             else:
                 igemm_lstm(x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks)
         if need_grad:
@@ -864,21 +878,26 @@ class ConvLSTMSeq(torch.autograd.Function):
         # f32 atomics into dh (read back as f32 by the next step's point-wise kernel); else a plain bf16 store.
         ksplit = split_k_factor(pixels, ddh.N, ddh.Ktot // 64)
         rec_dtype = F32 if ksplit > 1 else BF16
-        # split-K accumulators are zeroed once; the point-wise kernel clears the one it consumes (mode 2), and the same
-        # buffer is accumulated into again two timesteps later
-        buf = [(torch.zeros if ksplit > 1 else torch.empty)((B, H, W, Hdp), dtype=rec_dtype, device=dev) for _ in range(2)]
+        # split-K: one f32 slab per K range, plain stores; the point-wise kernel of the next (earlier) timestep adds them.
+        # Two buffers alternate so that step t's GEMM never writes what step t+1's point-wise kernel still reads.
+        nsl = ksplit_used(ddh.Ktot, ksplit) if ksplit > 1 else 1
+        if ksplit > 1:
+            buf = [torch.empty((nsl, B, H, W, Hdp), dtype=F32, device=dev) for _ in range(2)]
+        else:
+            buf = [torch.empty((B, H, W, Hdp), dtype=BF16, device=dev) for _ in range(2)]
         need_h0 = ctx.needs_input_grad[1]
         for t in range(T - 1, -1, -1):
             c_prev = c_hist[t] if (has_c0 or t > 0) else None
             L.check(L.lib.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
                                                     _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec),
-                                                    2 if ksplit > 1 else 0, _p(dc),
+                                                    1 if ksplit > 1 else 0, nsl, pixels * Hdp, _p(dc),
                                                     int(dc_zero), _p(dgates[t]), pixels, Hdp, _stream()), "lstm_bwd_pointwise")
             dc_zero = False
             if t > 0 or need_h0:
                 dh_rec = buf[t & 1]
                 if ksplit > 1:
-                    igemm_atomic([SrcView(dgates[t])], wd_h, (H, W), B, dh_rec.view(pixels, Hdp), ksplit, ktap=ks, pad=ks // 2)
+                    igemm_atomic([SrcView(dgates[t])], wd_h, (H, W), B, dh_rec.view(nsl, pixels, Hdp), ksplit, ktap=ks, pad=ks // 2,
+                                 slabs=True)
                 else:
                     igemm_store([SrcView(dgates[t])], wd_h, (H, W), B, [(dh_rec, 0, ddh.N, 0, 1, 0, 0)], ktap=ks, pad=ks // 2)
         dg_flat = dgates.view(T * B, H, W, 4 * Hdp)
@@ -899,7 +918,7 @@ class ConvLSTMSeq(torch.autograd.Function):
             dx_all = torch.empty_like(x_all)
             igemm_store([SrcView(dg_flat)], wd_x, (H, W), T * B, [(dx_all.view(T * B, H, W, Cxp), 0, ddx.N, 0, 1, 0, 0)], ktap=ks,
                         pad=ks // 2)
-        dh0 = (dh_rec if dh_rec.dtype == BF16 else dh_rec.to(BF16)) if need_h0 else None
+        dh0 = (dh_rec if dh_rec.dtype == BF16 else dh_rec.sum(dim=0).to(BF16)) if need_h0 else None
         dc0 = dc if (has_c0 and ctx.needs_input_grad[2]) else None
         return dx_all, dh0, dc0, dweight, dbias, None, None, None
 
