@@ -131,8 +131,14 @@ typedef struct {
     float* dwp;
     int32_t splits;
     int32_t accumulate;
+    int64_t slab;     /* 0: pixel ranges ADD into dwp with f32 atomics (dwp zeroed by the caller).  > 0 (>= N*Ktot): range r
+                       * STORES its partial panel to dwp + r*slab (floats), nothing needs zeroing, and uclstm_unpack_wgrad adds
+                       * the uclstm_igemm_wgrad_splits() slabs (float atomics ~1.3 TB/s, stores ~6 TB/s on MI355X). */
 } uclstm_wgrad_desc;
 int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream);
+/* Pixel ranges (= slabs in slab mode) the launch above will use for this descriptor; d->dwp may be NULL.  Call it with
+ * splits = 0, size dwp as [result][N][Ktot], then launch with splits = result. */
+int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d);
 
 /* ------------------------------------------------------------------------------------ */
 /* Weight panels                                                                        */
@@ -161,7 +167,8 @@ typedef struct {
 int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream);
 /* f32 panel gradient [N][Ktot] -> f32 gradient in the reference layout:
  * grad = (accumulate ? grad : 0) + dWp  on every valid element. */
-int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, float* grad, int32_t accumulate, void* stream);
+int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab /* dWp = sum of nslab slabs */,
+                            int64_t slab /* floats between slabs */, float* grad, int32_t accumulate, void* stream);
 /* bias [n_valid*(4 if LSTM)] f32 -> panel-row order [N] f32 (zero padded). */
 int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, void* stream);
 

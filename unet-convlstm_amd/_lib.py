@@ -61,7 +61,7 @@ class WgradDesc(C.Structure):
                 ("src", Src * 2),
                 ("N", C.c_int32), ("Ktot", C.c_int32),
                 ("nseg", C.c_int32), ("seg", Seg * 4),
-                ("dwp", C.c_void_p), ("splits", C.c_int32), ("accumulate", C.c_int32)]
+                ("dwp", C.c_void_p), ("splits", C.c_int32), ("accumulate", C.c_int32), ("slab", C.c_int64)]
 
 
 class PackDesc(C.Structure):
@@ -82,8 +82,9 @@ _PROTOS = {
     "uclstm_igemm_fwd": [C.POINTER(IgemmDesc), _P],
     "uclstm_igemm_ksplit_used": [_I, _I],
     "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
+    "uclstm_igemm_wgrad_splits": [C.POINTER(WgradDesc)],
     "uclstm_pack_weights": [C.POINTER(PackDesc), _P, _P, _P],
-    "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _P, _I, _P],
+    "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _I, _L, _P, _I, _P],
     "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],
     "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     "uclstm_bn_apply_relu": [_P, _P, _P, _P, _L, _L, _I, _P],

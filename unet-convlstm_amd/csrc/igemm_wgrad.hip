@@ -218,8 +218,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const uclstm_wgrad_
             for (int pr = tid >> 7; pr < 64; pr += 2) {
                 const int n = n0 + half * 64 + pr;
                 if (n < d.N)
-                    __hip_atomic_fetch_add(d.dwp + (long)n * d.Ktot + k, At[pr * AP + (tid & 127)], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    {
+                    float* dst = d.dwp + (long)sp * d.slab + (long)n * d.Ktot + k;
+                    if (d.slab > 0) *dst = At[pr * AP + (tid & 127)];        // this pixel range's own slab (added up by the unpack kernel)
+                    else __hip_atomic_fetch_add(dst, At[pr * AP + (tid & 127)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
@@ -444,8 +447,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
             for (int pr = tid / TCc; pr < 64; pr += 256 / TCc) {
                 const int n = n0 + half * 64 + pr;
                 if (n < d.N)
-                    __hip_atomic_fetch_add(d.dwp + (long)n * d.Ktot + k, At[pr * AP + col], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    {
+                    float* dst = d.dwp + (long)sp * d.slab + (long)n * d.Ktot + k;
+                    if (d.slab > 0) *dst = At[pr * AP + col];        // this pixel range's own slab (added up by the unpack kernel)
+                    else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
@@ -686,7 +692,11 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
             for (int pr = tid >> 8; pr < 64; pr += 2) {
                 const int n = n0 + mh * 128 + pwr * 64 + pr;
                 if (n < d.N)
-                    __hip_atomic_fetch_add(d.dwp + (long)n * d.Ktot + k, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    {
+                    float* dst = d.dwp + (long)sp * d.slab + (long)n * d.Ktot + k;
+                    if (d.slab > 0) *dst = At[pr * AP + col];        // this pixel range's own slab (added up by the unpack kernel)
+                    else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
@@ -695,7 +705,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
 }
 
 // splits for the one-block-per-CU kernel: whole rounds of 256 blocks, ~12 stages' worth of fixed cost per block
-int auto_splits256(int64_t tiles, int64_t stages) {
+int auto_splits256(int64_t tiles, int64_t stages, bool slabs) {
+    const int64_t fixed = slabs ? 8 : 28;     // 256 KiB per block: ~50 us of float atomics vs ~11 us of stores; a stage is ~1.9 us
     int best = 1;
     int64_t best_cost = -1;
     const int64_t smax = stages / 8 > 1 ? stages / 8 : 1;
@@ -703,7 +714,7 @@ int auto_splits256(int64_t tiles, int64_t stages) {
         const int64_t per = (stages + s - 1) / s;
         const int64_t used = (stages + per - 1) / per;
         const int64_t rounds = (tiles * used + 255) / 256;
-        const int64_t cost = rounds * (per + 12);
+        const int64_t cost = rounds * (per + fixed);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = (int)s;
@@ -714,7 +725,8 @@ int auto_splits256(int64_t tiles, int64_t stages) {
 
 // Pixel-range splits: minimise (rounds of the 512 resident blocks) x (stages per block + fixed cost of a block's
 // prologue and its 64-KiB atomic epilogue, ~8 stages' worth).
-int auto_splits(int64_t tiles, int64_t stages) {
+int auto_splits(int64_t tiles, int64_t stages, bool slabs) {
+    const int64_t fixed = slabs ? 4 : 8;      // a block's prologue + epilogue in stages' worth (atomics cost ~2x the stores)
     int best = 1;
     int64_t best_cost = -1;
     const int64_t smax = stages / 4 > 1 ? stages / 4 : 1;
@@ -722,7 +734,7 @@ int auto_splits(int64_t tiles, int64_t stages) {
         const int64_t per = (stages + s - 1) / s;
         const int64_t used = (stages + per - 1) / per;      // splits that actually get pixels
         const int64_t rounds = (tiles * used + 511) / 512;
-        const int64_t cost = rounds * (per + 8);
+        const int64_t cost = rounds * (per + fixed);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = (int)s;
@@ -752,12 +764,15 @@ bool wsrc_ok(const uclstm_src& s) {
 
 }  // namespace
 
-extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream) {
+namespace {
+// plan_only: validate, choose kernel + splits and return the split count without launching (dwp may be null)
+int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
     if (!dp) return UCLSTM_E_BADARG;
     const uclstm_wgrad_desc& d = *dp;
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0) return UCLSTM_E_BADARG;
     if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
-    if (d.nsrc < 1 || d.nsrc > 2 || !d.dwp || d.N <= 0 || (d.N % 8) || d.splits < 0) return UCLSTM_E_BADARG;
+    if (d.nsrc < 1 || d.nsrc > 2 || (!d.dwp && !plan_only) || d.N <= 0 || (d.N % 8) || d.splits < 0 || d.slab < 0) return UCLSTM_E_BADARG;
+    if (d.slab > 0 && d.slab < (int64_t)d.N * d.Ktot) return UCLSTM_E_BADARG;
     if (d.nseg < 1 || d.nseg > 4) return UCLSTM_E_BADARG;
     bool plain = d.scale == 1;
     for (int s = 0; s < d.nsrc; ++s) {
@@ -812,12 +827,15 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
     dv.n_nt = (d.N + tn - 1) / tn;
     dv.kt_per_tap = (fast && ((dv.kseg0 + dv.kseg1) % tc) == 0) ? (dv.kseg0 + dv.kseg1) / tc : 0;
     uclstm_wgrad_desc dd = d;
+    const bool slabs = d.slab > 0;
     if (dd.splits <= 0)
-        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP)
-                        : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP);
+        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs)
+                        : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs);
     long chunk = (dv.M + dd.splits - 1) / dd.splits;
     chunk = (chunk + TP - 1) / TP * TP;
     dv.chunk = chunk;
+    dd.splits = (int)((dv.M + chunk - 1) / chunk);          // every split owns pixels (slab mode: every slab is written)
+    if (plan_only) return dd.splits;
     const int64_t nblk = (int64_t)dv.n_kt * dv.n_nt * dd.splits;
     if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -849,3 +867,8 @@ extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* dp, void* stream)
         UCLSTM_LAUNCH(igemm_wgrad_kernel<false>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, st, dd, dv);
     return UCLSTM_OK;
 }
+}  // namespace
+
+extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream) { return wgrad_run(d, stream, false); }
+
+extern "C" int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d) { return wgrad_run(d, nullptr, true); }

@@ -73,13 +73,18 @@ __global__ void pack_kernel(const uclstm_pack_desc d, const float* __restrict__ 
     }
 }
 
-__global__ void unpack_kernel(const uclstm_pack_desc d, const float* __restrict__ dwp, float* __restrict__ grad, int accumulate) {
+__global__ void unpack_kernel(const uclstm_pack_desc d, const float* __restrict__ dwp, int nslab, int64_t slab, float* __restrict__ grad,
+                              int accumulate) {
     const int64_t total = (int64_t)d.N * d.Ktot;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / d.Ktot);
         const int k = (int)(idx - (int64_t)n * d.Ktot);
         const Decoded r = decode(d, n, k);
-        if (r.valid) grad[r.off] = (accumulate ? grad[r.off] : 0.f) + dwp[idx];
+        if (r.valid) {
+            float v = dwp[idx];
+            for (int sl = 1; sl < nslab; ++sl) v += dwp[sl * slab + idx];      // partial panels of the pixel ranges
+            grad[r.off] = (accumulate ? grad[r.off] : 0.f) + v;
+        }
     }
 }
 
@@ -114,9 +119,10 @@ extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, float* grad, int32_t accumulate, void* stream) {
-    if (!desc_ok(d) || !dwp || !grad) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, dwp, grad, accumulate);
+extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab, int64_t slab, float* grad,
+                                       int32_t accumulate, void* stream) {
+    if (!desc_ok(d) || !dwp || !grad || nslab < 1 || (nslab > 1 && slab < (int64_t)d->N * d->Ktot)) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, dwp, nslab, slab, grad, accumulate);
     return UCLSTM_OK;
 }
 

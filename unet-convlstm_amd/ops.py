@@ -243,9 +243,15 @@ def pack_bias(desc: L.PackDesc, b: torch.Tensor) -> torch.Tensor:
 
 
 def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """dwp: f32 panel gradient [N, Ktot] or its per-pixel-range slabs [splits, N, Ktot] (added up here)."""
     grad = torch.empty_like(like, dtype=F32, memory_format=torch.contiguous_format)
-    L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), _p(grad), 0, _stream()), "unpack_wgrad")
+    ns, st = _slabs_of(dwp)
+    L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), ns, st, _p(grad), 0, _stream()), "unpack_wgrad")
     return grad
+
+
+def _slabs_of(dwp: torch.Tensor) -> Tuple[int, int]:
+    return (dwp.shape[0], dwp.stride(0)) if dwp.dim() == 3 else (1, 0)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -296,7 +302,8 @@ def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[to
     side.wait_stream(main)                      # dz / activations produced so far are visible to the side stream
     with torch.cuda.stream(side):
         dwp = run_gemm()
-        L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), _p(g), 1, _stream()), "unpack_wgrad(accumulate)")
+        ns, st = _slabs_of(dwp)
+        L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), ns, st, _p(g), 1, _stream()), "unpack_wgrad(accumulate)")
         for t in inputs:
             if t is not None:
                 t.record_stream(side)           # the caching allocator must not recycle them under the side stream
@@ -456,7 +463,6 @@ def arena(device) -> ZeroArena:
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
                 pad: int = 0) -> torch.Tensor:
     dev = srcs[0].t.device
-    dwp = arena(dev).take((N, Ktot), dev)
     d = L.WgradDesc()
     d.n_img, d.H, d.W = n_img, out_hw[0], out_hw[1]
     d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
@@ -466,13 +472,19 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     d.nseg = len(dy_segs)
     for i, sg in enumerate(dy_segs):
         _fill_seg(d.seg[i], *sg)
-    d.dwp = dwp.data_ptr()
     taps = ktap * ktap
-    d.splits = 0              # 0 = the library picks the pixel-range splits for its tile shape (igemm_wgrad.hip auto_splits)
-    d.accumulate = 1
+    # slab mode: every pixel range stores its partial panel into its own slab (no float atomics, nothing to zero);
+    # the library picks the range count for its tile shape and the 256 CUs, uclstm_unpack_wgrad adds the slabs
+    d.splits, d.accumulate, d.slab = 0, 1, N * Ktot
+    splits = int(L.lib.uclstm_igemm_wgrad_splits(C.byref(d)))
+    if splits < 1:
+        raise L.UclstmError(f"igemm_wgrad: bad descriptor (code {splits})")
+    dwp = torch.empty((splits, N, Ktot), dtype=F32, device=dev)
+    d.splits = splits
+    d.dwp = dwp.data_ptr()
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
     _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap}")
+           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={splits}")
     return dwp
 
 
