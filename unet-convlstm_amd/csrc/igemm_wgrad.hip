@@ -705,7 +705,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
 }
 
 // splits for the one-block-per-CU kernel: whole rounds of 256 blocks, ~12 stages' worth of fixed cost per block
-int auto_splits256(int64_t tiles, int64_t stages, bool slabs) {
+int auto_splits256(int64_t tiles, int64_t stages, bool slabs, int64_t panel_elems) {
+    const double slab_cost = slabs ? (double)panel_elems * 8.0 / 4e12 / 1.9e-6 : 0.0;      // see auto_splits; a stage is ~1.9 us here
     const int64_t fixed = slabs ? 8 : 28;     // 256 KiB per block: ~50 us of float atomics vs ~11 us of stores; a stage is ~1.9 us
     int best = 1;
     int64_t best_cost = -1;
@@ -714,7 +715,7 @@ int auto_splits256(int64_t tiles, int64_t stages, bool slabs) {
         const int64_t per = (stages + s - 1) / s;
         const int64_t used = (stages + per - 1) / per;
         const int64_t rounds = (tiles * used + 255) / 256;
-        const int64_t cost = rounds * (per + fixed);
+        const int64_t cost = rounds * (per + fixed) + (int64_t)(slab_cost * (double)used);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = (int)s;
@@ -725,7 +726,10 @@ int auto_splits256(int64_t tiles, int64_t stages, bool slabs) {
 
 // Pixel-range splits: minimise (rounds of the 512 resident blocks) x (stages per block + fixed cost of a block's
 // prologue and its 64-KiB atomic epilogue, ~8 stages' worth).
-int auto_splits(int64_t tiles, int64_t stages, bool slabs) {
+int auto_splits(int64_t tiles, int64_t stages, bool slabs, int64_t panel_elems) {
+    // every extra slab is written here and read back by the unpack kernel: ~8 B per panel element at ~4 TB/s, in units of a
+    // block-stage (~1.3 us for this kernel)
+    const double slab_cost = slabs ? (double)panel_elems * 8.0 / 4e12 / 1.3e-6 : 0.0;
     const int64_t fixed = slabs ? 4 : 8;      // a block's prologue + epilogue in stages' worth (atomics cost ~2x the stores)
     int best = 1;
     int64_t best_cost = -1;
@@ -734,7 +738,7 @@ int auto_splits(int64_t tiles, int64_t stages, bool slabs) {
         const int64_t per = (stages + s - 1) / s;
         const int64_t used = (stages + per - 1) / per;      // splits that actually get pixels
         const int64_t rounds = (tiles * used + 511) / 512;
-        const int64_t cost = rounds * (per + fixed);
+        const int64_t cost = rounds * (per + fixed) + (int64_t)(slab_cost * (double)used);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = (int)s;
@@ -829,8 +833,8 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
     uclstm_wgrad_desc dd = d;
     const bool slabs = d.slab > 0;
     if (dd.splits <= 0)
-        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs)
-                        : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs);
+        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs, (int64_t)d.N * d.Ktot)
+                        : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs, (int64_t)d.N * d.Ktot);
     long chunk = (dv.M + dd.splits - 1) / dd.splits;
     chunk = (chunk + TP - 1) / TP * TP;
     dv.chunk = chunk;
