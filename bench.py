@@ -209,8 +209,18 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             fl, ms, n = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+            # --pmc WRITE_SIZE in separate runs of this same command, gfx950 correction applied: tools/pmc_traffic.py)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
+            if (a.base_ch, skip, a.size, a.seq, a.batch) == (64, True, 64, 20, 32) and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath))["kernels"][dom]["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n, "timing": "HIP events, one serialised step (side stream off)",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/round1_hbm_traffic.json)", "launches": n, "timing": "HIP events, one serialised step (side stream off)",
                     "avg_launch_ms": round(ms / n, 4),
                     "all": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
                             for k, v in agg.items()}}
