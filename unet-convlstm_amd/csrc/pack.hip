@@ -12,7 +12,22 @@ struct Decoded {
     int64_t off;
 };
 
-__device__ __forceinline__ bool decode_n(const uclstm_pack_desc& d, int n, int& n_ent, int& tapn) {
+// Magic-number divisors of a descriptor (computed once on the host): the per-element kernels are bound by their index
+// decode, and runtime 32/64-bit integer division costs tens of instructions each on this ISA.
+struct PackDiv {
+    FastDiv ktot, per_tap, n_cp, k_hdp, k_hd;
+};
+PackDiv make_pack_div(const uclstm_pack_desc& d) {
+    PackDiv v;
+    v.ktot = make_fastdiv((uint32_t)d.Ktot);
+    v.per_tap = make_fastdiv((uint32_t)(d.kseg[0] + d.kseg[1]));
+    v.n_cp = make_fastdiv((uint32_t)(d.n_cp > 0 ? d.n_cp : 1));
+    v.k_hdp = make_fastdiv((uint32_t)(d.k_hdp > 0 ? d.k_hdp : 1));
+    v.k_hd = make_fastdiv((uint32_t)(d.k_hd > 0 ? d.k_hd : 1));
+    return v;
+}
+
+__device__ __forceinline__ bool decode_n(const uclstm_pack_desc& d, const PackDiv& dv, int n, int& n_ent, int& tapn) {
     tapn = 0;
     if (d.n_mode == UCLSTM_NMODE_IDENTITY) {
         n_ent = n;
@@ -23,21 +38,21 @@ __device__ __forceinline__ bool decode_n(const uclstm_pack_desc& d, int n, int& 
         n_ent = gate * d.n_valid + hc;
         return hc < d.n_valid;
     } else {
-        tapn = n / d.n_cp;
+        tapn = (int)fdiv((uint32_t)n, dv.n_cp);
         const int co = n - tapn * d.n_cp;
         n_ent = co;
         return co < d.n_valid;
     }
 }
 
-__device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, int n, int k) {
+__device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, const PackDiv& dv, int n, int k) {
     Decoded r;
     r.valid = false;
     r.off = 0;
     int n_ent, tapn;
-    if (!decode_n(d, n, n_ent, tapn)) return r;
+    if (!decode_n(d, dv, n, n_ent, tapn)) return r;
     const int per_tap = d.kseg[0] + d.kseg[1];
-    int tap = k / per_tap;
+    int tap = (int)fdiv((uint32_t)k, dv.per_tap);
     const int kr = k - tap * per_tap;
     const int s = kr >= d.kseg[0] ? 1 : 0;
     const int c = s ? kr - d.kseg[0] : kr;
@@ -46,12 +61,12 @@ __device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, int n, int 
         if (c >= d.cvalid[s]) return r;
         k_ent = d.choff[s] + c;
     } else if (d.k_mode == UCLSTM_KMODE_GATES) {
-        const int gate = c / d.k_hdp;
+        const int gate = (int)fdiv((uint32_t)c, dv.k_hdp);
         const int hc = c - gate * d.k_hdp;
         if (gate >= 4 || hc >= d.k_hd) return r;
         k_ent = d.choff[s] + gate * d.k_hd + hc;
     } else {
-        const int tk = c / d.k_hd;
+        const int tk = (int)fdiv((uint32_t)c, dv.k_hd);
         if (tk >= d.k_hdp) return r;
         k_ent = c - tk * d.k_hd;
         tap = tk;
@@ -63,36 +78,42 @@ __device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, int n, int 
     return r;
 }
 
-__global__ void pack_kernel(const uclstm_pack_desc d, const float* __restrict__ w, bf16* __restrict__ wp) {
-    const int64_t total = (int64_t)d.N * d.Ktot;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / d.Ktot);
-        const int k = (int)(idx - (int64_t)n * d.Ktot);
-        const Decoded r = decode(d, n, k);
+__global__ void pack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w, bf16* __restrict__ wp) {
+    const uint32_t total = (uint32_t)d.N * (uint32_t)d.Ktot;       // < 2^31 (checked by the launcher)
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int n = (int)fdiv(idx, dv.ktot);
+        const int k = (int)(idx - (uint32_t)n * (uint32_t)d.Ktot);
+        const Decoded r = decode(d, dv, n, k);
         wp[idx] = f32_to_bf16(r.valid ? w[r.off] : 0.f);
     }
 }
 
-__global__ void unpack_kernel(const uclstm_pack_desc d, const float* __restrict__ dwp, int nslab, int64_t slab, float* __restrict__ grad,
-                              int accumulate) {
-    const int64_t total = (int64_t)d.N * d.Ktot;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / d.Ktot);
-        const int k = (int)(idx - (int64_t)n * d.Ktot);
-        const Decoded r = decode(d, n, k);
-        if (r.valid) {
-            float v = dwp[idx];
-            for (int sl = 1; sl < nslab; ++sl) v += dwp[sl * slab + idx];      // partial panels of the pixel ranges
-            grad[r.off] = (accumulate ? grad[r.off] : 0.f) + v;
+// grid.y > 1 (accumulate only): slab group blockIdx.y adds its share of the slabs with one f32 atomic per element -- for the
+// small panels whose weight gradient used hundreds of pixel ranges (first layer: 4096 elements x ~1000 slabs), where one
+// thread per element would walk all the slabs serially.
+__global__ void unpack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ dwp, int nslab, int64_t slab,
+                              float* __restrict__ grad, int accumulate) {
+    const uint32_t total = (uint32_t)d.N * (uint32_t)d.Ktot;
+    const int per = (nslab + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(nslab, s0 + per);
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int n = (int)fdiv(idx, dv.ktot);
+        const int k = (int)(idx - (uint32_t)n * (uint32_t)d.Ktot);
+        const Decoded r = decode(d, dv, n, k);
+        if (r.valid && s0 < s1) {
+            float v = 0.f;
+            for (int sl = s0; sl < s1; ++sl) v += dwp[sl * slab + idx];      // partial panels of the pixel ranges
+            if (gridDim.y > 1) atomicAdd(grad + r.off, v);
+            else grad[r.off] = (accumulate ? grad[r.off] : 0.f) + v;
         }
     }
 }
 
-__global__ void pack_bias_kernel(const uclstm_pack_desc d, const float* __restrict__ b, float* __restrict__ bp) {
+__global__ void pack_bias_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ b, float* __restrict__ bp) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= d.N) return;
     int n_ent, tapn;
-    const bool ok = decode_n(d, n, n_ent, tapn);
+    const bool ok = decode_n(d, dv, n, n_ent, tapn);
     bp[n] = ok ? b[n_ent] : 0.f;
 }
 
@@ -102,6 +123,7 @@ bool desc_ok(const uclstm_pack_desc* d) {
     if (d->n_mode < 0 || d->n_mode > 2 || d->k_mode < 0 || d->k_mode > 2) return false;
     if (d->n_mode == UCLSTM_NMODE_TAPMAJOR && d->n_cp <= 0) return false;
     if (d->k_mode != UCLSTM_KMODE_IDENTITY && (d->k_hd <= 0 || d->k_hdp <= 0)) return false;
+    if ((int64_t)d->N * d->Ktot >= ((int64_t)1 << 31)) return false;
     return true;
 }
 
@@ -115,19 +137,27 @@ int grid_for(int64_t total) {
 
 extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream) {
     if (!desc_ok(d) || !w || !wp) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, w, (bf16*)wp);
+    UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab, int64_t slab, float* grad,
                                        int32_t accumulate, void* stream) {
     if (!desc_ok(d) || !dwp || !grad || nslab < 1 || (nslab > 1 && slab < (int64_t)d->N * d->Ktot)) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, dwp, nslab, slab, grad, accumulate);
+    // few elements, many slabs: spread the slabs over grid.y (atomic accumulate) until the launch has ~1024 blocks
+    const int gx = grid_for((int64_t)d->N * d->Ktot);
+    int gy = 1;
+    if (accumulate && nslab >= 16 && gx < 512) {
+        gy = 1024 / gx;
+        if (gy > nslab / 4) gy = nslab / 4;
+        if (gy < 1) gy = 1;
+    }
+    UCLSTM_LAUNCH(unpack_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), dwp, nslab, slab, grad, accumulate);
     return UCLSTM_OK;
 }
 
 extern "C" int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, void* stream) {
     if (!desc_ok(d) || !b || !bp) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(pack_bias_kernel, dim3((d->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, b, bp);
+    UCLSTM_LAUNCH(pack_bias_kernel, dim3((d->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), b, bp);
     return UCLSTM_OK;
 }
