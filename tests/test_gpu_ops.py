@@ -373,11 +373,17 @@ def test_convlstm_cell_golden(tag):
     check_f32(cn.cpu(), f["c1_none"], "cell c1 (state=None)", l2=1e-2)
 
 
-def test_lstm_fused_kernel_and_split_k_form_agree():
+@pytest.mark.parametrize("B,H,W,Cx,Hd", [
+    (3, 9, 10, 24, 40),
+    # several row tiles: ragged pixel tile + partial row tile, a 64-aligned and a narrow source, more ranges than K-steps / 8
+    (3, 13, 11, 24, 72),
+    (2, 16, 16, 64, 64),
+    (5, 8, 8, 136, 128),
+])
+def test_lstm_fused_kernel_and_split_k_form_agree(B, H, W, Cx, Hd):
     """The fused cell kernel (gates in registers) and its split-K form (f32 atomic partial tiles + point-wise cell
     update, used when B*h*w is too small to fill the chip) compute the same step."""
     torch.manual_seed(9)
-    B, H, W, Cx, Hd = 3, 9, 10, 24, 40
     x, h = to_nhwc(torch.randn(B, Cx, H, W)), to_nhwc(torch.randn(B, Hd, H, W) * 0.5)
     c = torch.zeros(B, H, W, cpad(Hd), device=DEV)
     c[..., :Hd] = torch.randn(B, H, W, Hd, device=DEV) * 0.5
