@@ -170,7 +170,24 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
             load8f(shift + so, sh);
             load8f(mean + so, mu);
             load8f(rstd + so, rs);
-            for (int64_t p = p0 + prow; p < p1; p += cg.rows) {
+            int64_t p = p0 + prow;
+            for (; p + cg.rows < p1; p += 2 * cg.rows) {       // two pixel rows (four 16-byte loads) in flight
+                const uint4 za = z[p * cg.cpc + cc], ga = da[p * cg.cpc + cc];
+                const uint4 zb = z[(p + cg.rows) * cg.cpc + cc], gb = da[(p + cg.rows) * cg.cpc + cc];
+                float zv[8], gv[8], zw[8], gw[8];
+                unpack8(za, zv);
+                unpack8(ga, gv);
+                unpack8(zb, zw);
+                unpack8(gb, gw);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float g0 = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
+                    const float g1 = (zw[i] * sc[i] + sh[i] > 0.f) ? gw[i] : 0.f;
+                    s1[i] += g0 + g1;
+                    s2[i] += (g0 * (zv[i] - mu[i]) + g1 * (zw[i] - mu[i])) * rs[i];
+                }
+            }
+            for (; p < p1; p += cg.rows) {
                 float zv[8], gv[8];
                 unpack8(z[p * cg.cpc + cc], zv);
                 unpack8(da[p * cg.cpc + cc], gv);
@@ -199,6 +216,64 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
             if (ch < Cp) atomicAdd(sums + ((long)g * Cp + ch) * 2 + (j & 1), t);
         }
         __syncthreads();
+    }
+}
+
+// Same result as bn_bwd_apply_kernel below with the per-(group, channel) constants held in registers: a block owns a pixel
+// range of ONE group, a thread one 16-byte channel chunk of every `rows`-th pixel row, so
+//     dz = sc*(g_ - s1/n - xhat*s2/n) = sc*g_ + k1*z + k0,   k1 = -sc*rs*s2/n,  k0 = -sc*s1/n - k1*mu
+// costs two loads, one store and a handful of FMAs per chunk (the generic kernel re-loads ten float4 of constants per chunk).
+__global__ void bn_bwd_apply_cols_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ sums, uint4* __restrict__ dz,
+                                         int64_t ppg, int Cp, ColGeom cg, int blocks_per_group, int64_t pix_per_block, float inv_n) {
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
+    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    if ((int)threadIdx.x >= cg.active) return;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const long so = (long)g * Cp + cc * 8;
+    float sc[8], sh[8], k1[8], k0[8];
+    {
+        float mu[8], rs[8];
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s1 = sums[(so + i) * 2], s2 = sums[(so + i) * 2 + 1];
+            k1[i] = -sc[i] * rs[i] * s2 * inv_n;
+            k0[i] = -sc[i] * s1 * inv_n - k1[i] * mu[i];
+        }
+    }
+    int64_t p = p0 + prow;
+    for (; p + cg.rows < p1; p += 2 * cg.rows) {
+        const int64_t ia = p * cg.cpc + cc, ib = (p + cg.rows) * cg.cpc + cc;
+        const uint4 za = z[ia], ga = da[ia], zb = z[ib], gb = da[ib];
+        float zv[8], gv[8], zw[8], gw[8], oa[8], ob[8];
+        unpack8(za, zv);
+        unpack8(ga, gv);
+        unpack8(zb, zw);
+        unpack8(gb, gw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            oa[i] = ((zv[i] * sc[i] + sh[i] > 0.f) ? sc[i] * gv[i] : 0.f) + k1[i] * zv[i] + k0[i];
+            ob[i] = ((zw[i] * sc[i] + sh[i] > 0.f) ? sc[i] * gw[i] : 0.f) + k1[i] * zw[i] + k0[i];
+        }
+        dz[ia] = pack8(oa);
+        dz[ib] = pack8(ob);
+    }
+    for (; p < p1; p += cg.rows) {
+        const int64_t ia = p * cg.cpc + cc;
+        float zv[8], gv[8], oa[8];
+        unpack8(z[ia], zv);
+        unpack8(da[ia], gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) oa[i] = ((zv[i] * sc[i] + sh[i] > 0.f) ? sc[i] * gv[i] : 0.f) + k1[i] * zv[i] + k0[i];
+        dz[ia] = pack8(oa);
     }
 }
 
@@ -712,8 +787,8 @@ extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const flo
         return UCLSTM_E_BADARG;
     const ColGeom cg = col_geom(Cp);
     const int groups = (int)(pixels / pixels_per_group);
-    int bpg = (int)((pixels_per_group + 255) / 256);          // >= 256 pixel rows per block
-    const int cap = (2048 + groups - 1) / groups;
+    int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
+    const int cap = (4096 + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
     if (bpg < 1) bpg = 1;
     const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
@@ -731,6 +806,19 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
         return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    if (cg.cpc <= NT && (pixels % pixels_per_group) == 0) {
+        const int groups = (int)(pixels / pixels_per_group);
+        int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
+        const int cap = (4096 + groups - 1) / groups;
+        if (bpg > cap) bpg = cap;
+        if (bpg < 1) bpg = 1;
+        const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
+        UCLSTM_LAUNCH(bn_bwd_apply_cols_kernel, dim3(groups * bpg), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
+                      scale, shift, mean, rstd, sums, (uint4*)dz, pixels_per_group, Cp, cg, bpg, ppb,
+                      (float)(1.0 / (double)pixels_per_group));
+        return UCLSTM_OK;
+    }
     UCLSTM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, sums, (uint4*)dz, chunks, make_fastdiv(Cp / 8),
                        make_fastdiv((uint32_t)pixels_per_group), Cp, (float)(1.0 / (double)pixels_per_group));
