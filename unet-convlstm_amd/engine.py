@@ -165,6 +165,9 @@ def device_transform(ds, x_raw: torch.Tensor, y_raw: torch.Tensor):
 # step / epoch loops
 # ---------------------------------------------------------------------------------------------
 def _stack(output):
+    pre = getattr(output, "stacked", None)          # modules.SeqList: the frames as one [B,T,...] view of the kernel's output
+    if pre is not None:
+        return pre
     return torch.stack(output, dim=1) if isinstance(output, (list, tuple)) else output      # main.py:97-100
 
 

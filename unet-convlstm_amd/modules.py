@@ -223,6 +223,11 @@ class SpatialAttention(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # TemporalUNetDualView (reference train/unet.py:131-204)
 # ---------------------------------------------------------------------------------------------
+class SeqList(list):
+    """``list`` of per-timestep outputs with an optional ``stacked`` attribute: the same frames as one [B,T,...] view."""
+    stacked: Optional[Tensor] = None
+
+
 class TemporalUNetDualView(nn.Module):
     """Reference train/unet.py:131-204.
 
@@ -307,7 +312,11 @@ class TemporalUNetDualView(nn.Module):
         d1 = self.up1.forward_nhwc(d2, x1, c * 2, T)
         d0 = self.up0.forward_nhwc(d1, x0, c, T)
         y = self.outc.forward_nhwc(d0).view(T, B, self.out_channels, H, W)
-        out_seq = [y[t] for t in range(T)]
+        # a plain list of T frames like the reference's (train/unet.py:200-203); it also carries the frames already laid out
+        # as [B,T,C,H,W] (a view) so that the training loop's torch.stack(output, dim=1) costs no copy kernels and its backward
+        # is one transpose instead of T zero-fill + accumulate pairs
+        out_seq = SeqList(y.unbind(0))
+        out_seq.stacked = y.transpose(0, 1)
 
         new_state = [(ops.FromNHWC.apply(h, c * 16), ops.StateFromNHWC.apply(cc, c * 16)) for (h, cc) in new_st]
         return out_seq, new_state
