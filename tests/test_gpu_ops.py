@@ -248,9 +248,16 @@ def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
 # ---------------------------------------------------------------------------------------------
 # autograd operators vs oracle on bf16-rounded operands
 # ---------------------------------------------------------------------------------------------
-def test_conv_bn_relu_train_fwd_bwd_two_groups():
+@pytest.mark.parametrize("N,Ci,Co,H,W,groups", [
+    (4, 16, 24, 9, 8, 2),
+    # 64 -> 64 channels on 64-pixel-wide images: forward and input gradient take the persistent ring kernel
+    # (igemm_fwd_c64_kernel): image boundary every second tile / every tile, uneven tiles per block
+    (4, 64, 64, 8, 64, 2),
+    (6, 64, 64, 4, 64, 2),
+    (2, 64, 64, 64, 64, 2),
+])
+def test_conv_bn_relu_train_fwd_bwd_two_groups(N, Ci, Co, H, W, groups):
     torch.manual_seed(4)
-    N, Ci, Co, H, W, groups = 4, 16, 24, 9, 8, 2
     x = bf(torch.randn(N, Ci, H, W))
     w = bf(torch.randn(Co, Ci, 3, 3) * 0.2)
     b = torch.randn(Co) * 0.1
@@ -274,16 +281,20 @@ def test_conv_bn_relu_train_fwd_bwd_two_groups():
          "bn.num_batches_tracked": torch.tensor(0)}
     buf = {}
     outs = []
+    npg = N // groups
     for g in range(groups):
-        z = F.conv2d(xr[g * 2:(g + 1) * 2], wr, b, padding=1)
+        z = F.conv2d(xr[g * npg:(g + 1) * npg], wr, b, padding=1)
         outs.append(O.batchnorm_relu(z, p, "bn", True, buf))
     ref = torch.cat(outs)
     (ref * bf(go)).sum().backward()
     check_bf16(from_nhwc(a.detach(), Co), ref.detach(), "conv+bn+relu fwd", l2=6e-3, mx=2e-2)
-    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "conv+bn+relu dx", l2=1.5e-2, mx=5e-2)
+    # K = 576 sums of bf16-rounded dz: the largest single dx element and the (cancelling) dbeta sums sit a little higher on
+    # the 64-channel cases; the generic kernel gives the same figures to four digits (UCLSTM_FWD_C64=0)
+    big = Ci >= 64
+    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "conv+bn+relu dx", l2=1.5e-2, mx=1e-1 if big else 5e-2)
     check_f32(wg.grad.cpu(), wr.grad, "conv+bn+relu dW", l2=1.5e-2)
     check_f32(gg.grad.cpu(), gr.grad, "dgamma", l2=1e-2)
-    check_f32(bg.grad.cpu(), br.grad, "dbeta", l2=1e-2)
+    check_f32(bg.grad.cpu(), br.grad, "dbeta", l2=2e-2 if big else 1e-2)
     torch.testing.assert_close(rmg.cpu(), buf["bn.running_mean"], rtol=5e-3, atol=2e-3)
     torch.testing.assert_close(rvg.cpu(), buf["bn.running_var"], rtol=5e-3, atol=2e-3)
 

@@ -447,6 +447,271 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / pad 1 convolution with C_in = C_out = 64 on 64-pixel-wide images (the full-resolution level of the UNet at the
+// 64x64 configurations: 2.6 M pixels, K = 576 -- nine K-steps per tile, where the generic kernel spends as long in its
+// prologue/epilogue as in the loop and re-stages every activation row nine times through the LDS-DMA path: 545 TFLOP/s).
+// Persistent blocks, one per CU, 4 waves:
+//   * the whole weight panel (9 taps x 64 rows x 128 B = 72 KiB) stays resident in LDS;
+//   * activations live in a RING of ten image rows (66 pixels x 128 B each: the two halo columns are permanent zeros,
+//     rows above/below an image are zero-filled by out-of-range DMA); a tile is four image rows = 256 pixels, one row per
+//     wave; it reads six ring rows, and while it computes, the four new rows of the next tile are DMA'd into the four
+//     free slots -- every activation row is staged ONCE and all nine taps are shifted LDS reads;
+//   * the tile loop body (288 MFMA per wave) has no barrier; two barriers per tile (rows landed, statistics);
+//   * epilogue straight from registers: a lane holds 4 consecutive channels of a pixel, a wave store writes 32-byte
+//     sector-aligned pieces; BatchNorm partial sums by 16-lane shuffles + a 2-KiB LDS exchange.
+// Virtual row numbering: image k, row y -> v = k*(H+1) + y; v = k*(H+1) + H is the zero row shared by images k and k+1;
+// ring slot of v = (v + 1) mod 10.
+// Sum over the 16 lanes of a DPP row with four v_add_f32 + DPP (xor 1, xor 2, half-row mirror, row mirror); every lane of the
+// row ends up with the total.  (__shfl_xor would be four ds_bpermute round trips per value.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));     // row_mirror
+    return v;
+}
+
+constexpr int C64_WBYTES = 9 * 64 * 128;            // 73728
+constexpr int C64_ROW = 66 * 128;                   // 8448
+constexpr int C64_SLOTS = 10;
+constexpr int C64_RED = C64_WBYTES + C64_SLOTS * C64_ROW;      // 158208: [4 waves][64 channels][2] floats
+constexpr int C64_SMEM = C64_RED + 2 * 4 * 64 * 2 * 4;        // 162304 (two exchange buffers)
+
+__global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igemm_desc d, const int tiles_total, const int tiles_per_block,
+                                                                const uint32_t xbytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    unsigned char* Wl = smem;
+    unsigned char* Ring = smem + C64_WBYTES;
+    float* Red = (float*)(smem + C64_RED);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+    const int H = d.H;
+    const int tiles_per_img = H >> 2;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(tiles_total, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].ptr, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, (uint32_t)(64 * 576 * 2), 0x00020000);
+
+    // permanent zero halo columns (positions 0 and 65 of every ring row)
+    if (tid < C64_SLOTS * 2 * 8) {
+        const int sl = tid >> 4, side = (tid >> 3) & 1, ch = tid & 7;
+        *(uint4*)(Ring + sl * C64_ROW + side * 65 * 128 + ch * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // resident weight panel: instruction q covers tap q>>3, rows (q&7)*8 + (lane>>3); chunk position lane&7 <- chunk pos^(row&7)
+    {
+        const int srow = lane >> 3;
+        const int sc = (lane & 7) ^ srow;
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+            const int q = it * 4 + wave;
+            const int tp = q >> 3, nrow = (q & 7) * 8 + srow;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(Wl + q * 1024), 16, (uint32_t)(2 * (nrow * 576 + sc * 8)), (uint32_t)(tp * 128), 0,
+                                                     0);
+        }
+    }
+    // activation row staging: wave w moves pixels 8*(w + 4*i) + (lane>>3), i = 0,1, of a row; position p = x'+1 holds chunk pos^(p&7)
+    uint32_t rvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int xp = 8 * (wave + 4 * i) + (lane >> 3);
+        const int sc = (lane & 7) ^ ((xp + 1) & 7);
+        rvoff[i] = (uint32_t)(2 * (xp * 64 + sc * 8));
+    }
+    const uint32_t row_bytes = (uint32_t)(64 * 64 * 2);            // one image row
+    // cursor of the next virtual row to stage: (image lk, row ly in 0..H where H = the zero row), its ring slot.  Plain
+    // locals advanced by a macro: as by-reference lambda captures they ended up in scratch memory.
+    int lk = 0, ly = 0, lslot = 0, loaded = -2;
+#define C64_ISSUE_NEXT_ROW()                                                                                              \
+    {                                                                                                                     \
+        const bool zero_ = ly == H || lk < 0 || lk >= d.n_img;                                                            \
+        const uint32_t soff_ = zero_ ? 0u : (uint32_t)(lk * H + ly) * row_bytes;                                          \
+        unsigned char* dst_ = Ring + lslot * C64_ROW + 128;                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + wave * 1024), 16, zero_ ? OOB : rvoff[0], soff_, 0, 0);       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + (wave + 4) * 1024), 16, zero_ ? OOB : rvoff[1], soff_, 0, 0); \
+        ++loaded;                                                                                                         \
+        lslot = lslot == C64_SLOTS - 1 ? 0 : lslot + 1;                                                                   \
+        if (ly == H) { ly = 0; ++lk; } else { ++ly; }                                                                     \
+    }
+
+    // fragment read offsets
+    int xoff[4][3][2];          // [b][dx][ksub]: inside a ring row
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int pos = b * 16 + l15 + dx;
+                xoff[b][dx][kk] = pos * 128 + (((kk * 4 + lq) ^ (pos & 7)) << 4);
+            }
+    int woff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) woff[kk] = l15 * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
+
+    const uclstm_seg sg = d.seg[0];
+    // epilogue constants of this lane's channels a*16 + lq*4 .. +3 (loop invariant)
+    float bs[4][4], scl[4][4], sft[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = a * 16 + lq * 4;
+        const float4 t0 = d.bias ? *(const float4*)(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t1 = d.col_scale ? *(const float4*)(d.col_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 t2 = d.col_shift ? *(const float4*)(d.col_shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bs[a][0] = t0.x; bs[a][1] = t0.y; bs[a][2] = t0.z; bs[a][3] = t0.w;
+        scl[a][0] = t1.x; scl[a][1] = t1.y; scl[a][2] = t1.z; scl[a][3] = t1.w;
+        sft[a][0] = t2.x; sft[a][1] = t2.y; sft[a][2] = t2.z; sft[a][3] = t2.w;
+    }
+    // tile statistics: every wave leaves its row's sums in Red[tile parity]; the four rows are added and written out after
+    // the NEXT tile's "rows landed" barrier (no barrier of their own)
+    auto flush_stats = [&](int tile, int parity) {
+        if (tid < 128) {
+            const int n = tid >> 1, j = tid & 1;
+            const float* R = Red + parity * 512;
+            d.stats[((long)tile * d.N + n) * 2 + j] = R[(0 * 64 + n) * 2 + j] + R[(1 * 64 + n) * 2 + j] + R[(2 * 64 + n) * 2 + j] + R[(3 * 64 + n) * 2 + j];
+        }
+    };
+    int k = t_begin / tiles_per_img;
+    int tr = t_begin - k * tiles_per_img;
+    for (int tt = t_begin; tt < t_end; ++tt) {
+        const int v0 = k * (H + 1) + 4 * tr;
+        if (tt == t_begin) {      // cursor at virtual row v0 - 1
+            const int v = v0 - 1;
+            if (v < 0) { lk = -1; ly = H; } else { lk = v / (H + 1); ly = v - lk * (H + 1); }
+            lslot = (v + 1) % C64_SLOTS;
+            loaded = v - 1;
+        }
+        // rows this tile needs that were not prefetched (six at the start of the block, one after an image boundary)
+        while (loaded < v0 + 4) C64_ISSUE_NEXT_ROW()
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (d.stats && tt > t_begin) flush_stats(tt - 1, (tt - 1) & 1);
+        // prefetch for the next tile into the free slots (at most four rows: ten slots minus the six in use)
+        int k1 = k, tr1 = tr + 1;
+        if (tr1 == tiles_per_img) { tr1 = 0; ++k1; }
+        if (tt + 1 < t_end) {
+            const int upto = min(k1 * (H + 1) + 4 * tr1 + 4, loaded + 4);
+            while (loaded < upto) C64_ISSUE_NEXT_ROW()
+        }
+
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // 18 steps (tap, 32-channel half), software-pipelined by hand: the fragments of step s+1 are read while the 16 MFMAs of
+        // step s issue (one wave per SIMD: nobody else hides an LDS round trip), one ds_read slotted after each of the first
+        // eight MFMAs of a step
+        const unsigned char* rowp[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rowp[dy] = Ring + ((v0 + wave + dy) % C64_SLOTS) * C64_ROW;      // virtual row v0 + wave + dy - 1
+        bf16x8 wf[2][4], xf[2][4];
+        auto load_step = [&](int st, int set) {
+            const int tp = st >> 1, kk = st & 1;
+            const int dy = tp / 3, dx = tp - dy * 3;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[set][a] = *(const bf16x8*)(Wl + tp * 8192 + a * 2048 + woff[kk]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[set][b] = *(const bf16x8*)(rowp[dy] + xoff[b][dx][kk]);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st & 1][a], xf[st & 1][b], acc[a][b], 0, 0, 0);
+            if (st + 1 < 18) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);         // the other 8 MFMAs
+            }
+        }
+
+        // ---- epilogue from registers: wave = image row y, lane = (pixel b*16 + l15, channels a*16 + lq*4 .. +3) ----
+        const int y = 4 * tr + wave;
+        bf16* orow = (bf16*)sg.ptr + ((long)(k * H + y) * 64) * (long)sg.C + sg.c_off;
+        float s1[4][4], s2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int n = a * 16 + lq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[a][r] = s2[a][r] = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                Pack8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = (acc[a][b][r] + bs[a][r]) * scl[a][r] + sft[a][r];
+                    if (d.relu) v = fmaxf(v, 0.f);
+                    o.e[r] = f32_to_bf16(v);
+                    const float q = bf16_to_f32(o.e[r]);
+                    s1[a][r] += q;
+                    s2[a][r] += q * q;
+                }
+                if (n < sg.n_end) *(uint2*)(orow + (long)(b * 16 + l15) * sg.C + n) = o.u;
+            }
+        }
+        if (d.stats) {
+            // sum over the 16 pixels of a lane group (the 4 b-tiles are already summed), then over the 4 rows through LDS
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[a][r] = row16_sum(s1[a][r]);
+                    s2[a][r] = row16_sum(s2[a][r]);
+                }
+            if (l15 == 0) {
+                float* R = Red + (tt & 1) * 512;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = a * 16 + lq * 4 + r;
+                        R[(wave * 64 + n) * 2] = s1[a][r];
+                        R[(wave * 64 + n) * 2 + 1] = s2[a][r];
+                    }
+            }
+        }
+        k = k1;
+        tr = tr1;
+    }
+    if (d.stats) {
+        __syncthreads();
+        flush_stats(t_end - 1, (t_end - 1) & 1);
+    }
+#endif
+}
+
+#undef C64_ISSUE_NEXT_ROW
+
+// The launch conditions of igemm_fwd_c64_kernel (everything else takes the generic kernel).
+inline bool c64_ok(const uclstm_igemm_desc& d) {
+    static const bool off = [] { const char* e = getenv("UCLSTM_FWD_C64"); return e && e[0] == '0'; }();
+    if (off || d.epi != UCLSTM_EPI_STORE || d.nsrc != 1 || d.ktap != 3 || d.pad != 1 || d.scale != 1) return false;
+    const uclstm_src& S = d.src[0];
+    if (S.C != 64 || d.N != 64 || d.Ktot != 576 || d.W != 64 || (d.H & 3) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
+    if (d.nseg != 1) return false;
+    const uclstm_seg& g = d.seg[0];
+    if (g.scale != 1 || g.oy || g.ox || g.Hd != d.H || g.Wd != d.W || g.n_begin != 0 || g.n_end > 64 || (g.n_end % 4)) return false;
+    if ((int64_t)d.n_img * d.H * d.W * 64 * 2 >= ((int64_t)1 << 31) - (1 << 22)) return false;
+    if ((int64_t)d.n_img * (d.H + 1) >= ((int64_t)1 << 30)) return false;
+    return true;
+}
+
 bool src_ok(const uclstm_src& s) {
     return s.ptr && s.C > 0 && (s.C % 8) == 0 && s.Hs > 0 && s.Ws > 0 && ((uintptr_t)s.ptr % 16) == 0;
 }
@@ -566,6 +831,20 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     }
 
     hipStream_t st = (hipStream_t)stream;
+    if (c64_ok(d) && mg % 256 == 0) {        // its 256-pixel tiles are the generic 64x256 shape's tiles: same statistics rows
+        static bool attr64 = false;
+        if (!attr64) {
+            (void)hipFuncSetAttribute((const void*)igemm_fwd_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_SMEM);
+            attr64 = true;
+        }
+        const int tiles_total = d.n_img * (d.H / 4);
+        const int blocks = tiles_total < 256 ? tiles_total : 256;
+        const int per = (tiles_total + blocks - 1) / blocks;
+        const int grid = (tiles_total + per - 1) / per;
+        UCLSTM_LAUNCH(igemm_fwd_c64_kernel, dim3(grid), dim3(256), C64_SMEM, st, d, tiles_total, per,
+                      (uint32_t)((int64_t)d.n_img * d.H * d.W * 64 * 2));
+        return UCLSTM_OK;
+    }
     if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
     if (d.epi == UCLSTM_EPI_ATOMIC) return shp == 1 ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 0>(d, dv, nblk, st);
     if (shp == 1) return launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st);
