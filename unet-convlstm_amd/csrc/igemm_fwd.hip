@@ -476,10 +476,10 @@ constexpr int C64_WBYTES = 9 * 64 * 128;            // 73728
 constexpr int C64_ROW = 66 * 128;                   // 8448
 constexpr int C64_SLOTS = 10;
 constexpr int C64_RED = C64_WBYTES + C64_SLOTS * C64_ROW;      // 158208: [4 waves][64 channels][2] floats
-constexpr int C64_SMEM = C64_RED + 2 * 4 * 64 * 2 * 4;        // 162304 (two exchange buffers)
+constexpr int C64_SMEM = C64_RED + 4 * 64 * 2 * 4;            // 160256
 
 __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igemm_desc d, const int tiles_total, const int tiles_per_block,
-                                                                const uint32_t xbytes) {
+                                                                const uint32_t xbytes, const int tiles_per_group) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -570,15 +570,15 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         scl[a][0] = t1.x; scl[a][1] = t1.y; scl[a][2] = t1.z; scl[a][3] = t1.w;
         sft[a][0] = t2.x; sft[a][1] = t2.y; sft[a][2] = t2.z; sft[a][3] = t2.w;
     }
-    // tile statistics: every wave leaves its row's sums in Red[tile parity]; the four rows are added and written out after
-    // the NEXT tile's "rows landed" barrier (no barrier of their own)
-    auto flush_stats = [&](int tile, int parity) {
-        if (tid < 128) {
-            const int n = tid >> 1, j = tid & 1;
-            const float* R = Red + parity * 512;
-            d.stats[((long)tile * d.N + n) * 2 + j] = R[(0 * 64 + n) * 2 + j] + R[(1 * 64 + n) * 2 + j] + R[(2 * 64 + n) * 2 + j] + R[(3 * 64 + n) * 2 + j];
-        }
-    };
+    // BatchNorm partial sums: a lane keeps RUNNING sums of its channels over the block's consecutive tiles of one statistic
+    // group; only at the end of the run (group boundary or end of the block) are they reduced across lanes and waves and
+    // written into that tile's row -- the other tiles of the run get zero rows (every row of the partial-sum buffer must be
+    // written: the reduction kernel adds all rows of a group).  The cross-lane reduction per tile cost as much as the MFMAs.
+    float gs1[4][4], gs2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gs1[a][r] = gs2[a][r] = 0.f;
     int k = t_begin / tiles_per_img;
     int tr = t_begin - k * tiles_per_img;
     for (int tt = t_begin; tt < t_end; ++tt) {
@@ -593,7 +593,6 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         while (loaded < v0 + 4) C64_ISSUE_NEXT_ROW()
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (d.stats && tt > t_begin) flush_stats(tt - 1, (tt - 1) & 1);
         // prefetch for the next tile into the free slots (at most four rows: ten slots minus the six in use)
         int k1 = k, tr1 = tr + 1;
         if (tr1 == tiles_per_img) { tr1 = 0; ++k1; }
@@ -645,53 +644,82 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         const int y = 4 * tr + wave;
         bf16* orow = (bf16*)sg.ptr + ((long)(k * H + y) * 64) * (long)sg.C + sg.c_off;
         float s1[4][4], s2[4][4];
+        Pack8 ov[4][4];           // [a][b]: this lane's 4 channels of pixel b*16 + l15, bf16
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int n = a * 16 + lq * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) s1[a][r] = s2[a][r] = 0.f;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                Pack8 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = (acc[a][b][r] + bs[a][r]) * scl[a][r] + sft[a][r];
                     if (d.relu) v = fmaxf(v, 0.f);
-                    o.e[r] = f32_to_bf16(v);
-                    const float q = bf16_to_f32(o.e[r]);
+                    ov[a][b].e[r] = f32_to_bf16(v);
+                    const float q = bf16_to_f32(ov[a][b].e[r]);
                     s1[a][r] += q;
                     s2[a][r] += q * q;
                 }
-                if (n < sg.n_end) *(uint2*)(orow + (long)(b * 16 + l15) * sg.C + n) = o.u;
             }
         }
+        // 16-byte stores (guide T21: a row-per-lane epilogue of 8-byte stores is store-ISSUE bound): v_permlane16_swap trades
+        // quads between lane l (even 16-lane row, lq = 0/2) and l+16 (odd row) of the same pixel, so that the even lane
+        // holds 8 consecutive channels of row tile a and the odd lane 8 consecutive channels of row tile a+1.
+        const int nst0 = (lq & 1) ? 16 + (lq - 1) * 4 : lq * 4;       // + a*16 for the pair (a, a+1)
+#pragma unroll
+        for (int a = 0; a < 4; a += 2)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const auto p0 = __builtin_amdgcn_permlane16_swap(ov[a][b].u.x, ov[a + 1][b].u.x, false, false);
+                const auto p1 = __builtin_amdgcn_permlane16_swap(ov[a][b].u.y, ov[a + 1][b].u.y, false, false);
+                const int n = a * 16 + nst0;
+                if (n < sg.n_end) *(uint4*)(orow + (long)(b * 16 + l15) * sg.C + n) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+            }
         if (d.stats) {
-            // sum over the 16 pixels of a lane group (the 4 b-tiles are already summed), then over the 4 rows through LDS
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s1[a][r] = row16_sum(s1[a][r]);
-                    s2[a][r] = row16_sum(s2[a][r]);
+                    gs1[a][r] += s1[a][r];
+                    gs2[a][r] += s2[a][r];
                 }
-            if (l15 == 0) {
-                float* R = Red + (tt & 1) * 512;
+            const bool run_ends = tt + 1 == t_end || (tt + 1) / tiles_per_group != tt / tiles_per_group;      // block-uniform
+            if (!run_ends) {
+                if (tid < 128) d.stats[(long)tt * d.N * 2 + tid] = 0.f;
+            } else {
+                // sum over the 16 pixels of a lane row, then over the 4 waves through LDS
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int n = a * 16 + lq * 4 + r;
-                        R[(wave * 64 + n) * 2] = s1[a][r];
-                        R[(wave * 64 + n) * 2 + 1] = s2[a][r];
+                        gs1[a][r] = row16_sum(gs1[a][r]);
+                        gs2[a][r] = row16_sum(gs2[a][r]);
                     }
+                if (l15 == 0) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = a * 16 + lq * 4 + r;
+                            Red[(wave * 64 + n) * 2] = gs1[a][r];
+                            Red[(wave * 64 + n) * 2 + 1] = gs2[a][r];
+                        }
+                }
+                __syncthreads();
+                if (tid < 128) {
+                    const int n = tid >> 1, j = tid & 1;
+                    d.stats[((long)tt * d.N + n) * 2 + j] =
+                        Red[(0 * 64 + n) * 2 + j] + Red[(1 * 64 + n) * 2 + j] + Red[(2 * 64 + n) * 2 + j] + Red[(3 * 64 + n) * 2 + j];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gs1[a][r] = gs2[a][r] = 0.f;
+                // (Red is rewritten only after the next run's tiles, each of which starts with a barrier)
             }
         }
         k = k1;
         tr = tr1;
-    }
-    if (d.stats) {
-        __syncthreads();
-        flush_stats(t_end - 1, (t_end - 1) & 1);
     }
 #endif
 }
@@ -706,7 +734,9 @@ inline bool c64_ok(const uclstm_igemm_desc& d) {
     if (S.C != 64 || d.N != 64 || d.Ktot != 576 || d.W != 64 || (d.H & 3) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
     if (d.nseg != 1) return false;
     const uclstm_seg& g = d.seg[0];
-    if (g.scale != 1 || g.oy || g.ox || g.Hd != d.H || g.Wd != d.W || g.n_begin != 0 || g.n_end > 64 || (g.n_end % 4)) return false;
+    if (g.scale != 1 || g.oy || g.ox || g.Hd != d.H || g.Wd != d.W || g.n_begin != 0 || g.n_end > 64 || (g.n_end % 8) || (g.C % 8) ||
+        (g.c_off % 8))
+        return false;
     if ((int64_t)d.n_img * d.H * d.W * 64 * 2 >= ((int64_t)1 << 31) - (1 << 22)) return false;
     if ((int64_t)d.n_img * (d.H + 1) >= ((int64_t)1 << 30)) return false;
     return true;
@@ -842,7 +872,7 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
         const int per = (tiles_total + blocks - 1) / blocks;
         const int grid = (tiles_total + per - 1) / per;
         UCLSTM_LAUNCH(igemm_fwd_c64_kernel, dim3(grid), dim3(256), C64_SMEM, st, d, tiles_total, per,
-                      (uint32_t)((int64_t)d.n_img * d.H * d.W * 64 * 2));
+                      (uint32_t)((int64_t)d.n_img * d.H * d.W * 64 * 2), dv.tpg);
         return UCLSTM_OK;
     }
     if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
