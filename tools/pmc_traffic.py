@@ -17,6 +17,8 @@ def family(name: str) -> str:
     m = re.search(r"igemm_fwd_kernel<(\d), (\d), (\d)>", name)
     if m:
         return {"0": "igemm_fwd_store", "1": "igemm_fwd_lstm", "2": "igemm_fwd_atomic"}[m.group(1)]
+    if "igemm_fwd_c64" in name:        # the persistent 64-channel kernel serves UCLSTM_EPI_STORE launches
+        return "igemm_fwd_store"
     if "igemm_wgrad" in name:
         return "igemm_wgrad"
     m = re.search(r"(\w+_kernel)", name)
