@@ -68,7 +68,7 @@ def cpu_baseline(base_ch: int, skip: bool, size: int):
     torch.manual_seed(0)
     m = U.TemporalUNetDualView(1, 1, base_ch=base_ch, use_skip_lstm=skip)          # parameter container only (CPU)
     p = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    B, T = 2, 4
+    B, T = 4, 8          # ~12 s of CPU work on 16 threads
     log(f"cpu_baseline: oracle training step on {cores} host threads, B={B} T={T} ...")
     g = torch.Generator().manual_seed(1)
     x = torch.rand((B, T, 2, size, size), generator=g)
@@ -178,14 +178,16 @@ def main():
     lossv = float(loss)
 
     roof = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
         # One instrumented step with every kernel on the launch stream: with the weight-gradient GEMMs overlapping on
         # their side stream the events around a forward GEMM would also count the time it shares the CUs with them.
+        # EVERY rank runs it (the step contains the gradient all-reduce); only rank 0 records events.
         async_was, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
-        ops.PROFILE = []
+        ops.PROFILE = [] if rank == 0 else None
         step()
         torch.cuda.synchronize()
         ops.ASYNC_WGRAD = async_was
+    if not a.no_roofline and rank == 0:
         agg = {}
         rows = []
         for kind, flops, e0, e1, note in ops.PROFILE:
