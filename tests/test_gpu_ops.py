@@ -162,6 +162,41 @@ def test_conv3x3_forward_512_thread_shape_three_stage_ring():
     assert r.returncode == 0
 
 
+def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path):
+    """The persistent 64-channel kernel accumulates in the same order as the generic one (taps 0..8, two 32-channel halves
+    each): outputs must be bit-identical, the per-group statistics equal up to f32 summation order.  The generic kernel
+    runs in a subprocess with UCLSTM_FWD_C64=0 (the switch is read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        import unet_convlstm_amd as U
+        from unet_convlstm_amd import ops
+        torch.manual_seed(21)
+        N, H, W, groups = 6, 12, 64, 3
+        xn = (torch.randn(N, H, W, 64) * 0.7).to(torch.bfloat16).cuda()
+        w = (torch.randn(64, 64, 3, 3) * 0.1).cuda()
+        b = (torch.randn(64) * 0.3).cuda()
+        pd = ops.conv_pack_desc(64, 64, [64], [64])
+        wp, bp = ops.pack_weights(pd, w), ops.pack_bias(pd, b)
+        out = torch.empty(N, H, W, 64, dtype=torch.bfloat16, device="cuda")
+        tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups, 64)
+        stats = torch.full((groups, tpg, 64, 2), float("nan"), device="cuda")
+        ops.igemm_store([ops.SrcView(xn)], wp, (H, W), N, [(out, 0, 64, 0, 1, 0, 0)], ktap=3, pad=1, groups=groups, bias=bp, stats=stats)
+        torch.save({"out": out.cpu(), "stats": stats.sum(1).cpu()}, sys.argv[1])
+    """ % ROOT_DIR)
+    res = {}
+    for tag, val in (("ring", "1"), ("generic", "0")):
+        f = str(tmp_path / (tag + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, UCLSTM_FWD_C64=val), capture_output=True, text=True,
+                           timeout=240)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[tag] = torch.load(f)
+    assert torch.equal(res["ring"]["out"], res["generic"]["out"])
+    assert bool(torch.isfinite(res["ring"]["stats"]).all())
+    torch.testing.assert_close(res["ring"]["stats"], res["generic"]["stats"], rtol=1e-4, atol=1e-2)
+
+
 def test_conv3x3_padded_second_source_and_groups_stats():
     """cat([skip, up]) with the upsampled map smaller than the skip (F.pad offsets) + per-group BN partial sums."""
     torch.manual_seed(2)
