@@ -126,42 +126,6 @@ def test_conv3x3_forward(N, C0, C1, Co, H, W):
     assert pad_is_zero(out, Co)
 
 
-def test_conv3x3_forward_512_thread_shape_three_stage_ring():
-    """The 128x256 / 512-thread block shape (3-stage LDS ring, counted vmcnt, raw s_barrier) is off by default; force it
-    in a child process (the switch is read once per process) and check a layer large enough to select it."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent("""
-        import sys, torch, torch.nn.functional as F
-        sys.path.insert(0, %r)
-        import unet_convlstm_amd as U
-        from unet_convlstm_amd import ops
-        torch.manual_seed(5)
-        N, C, Co, H = 8, 64, 128, 128
-        x = torch.randn(N, C, H, H).bfloat16().float()
-        w = (torch.randn(Co, C, 3, 3) * 0.1).bfloat16().float()
-        xn = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-        pd = ops.conv_pack_desc(Co, C, [C], [C])
-        wp = ops.pack_weights(pd, w.cuda())
-        out = torch.empty(N, H, H, Co, dtype=torch.bfloat16, device="cuda")
-        tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, H, 2, Co)
-        assert tpg == (N // 2) * H * H // 256, tpg
-        stats = torch.zeros(2, tpg, Co, 2, device="cuda")
-        ops.igemm_store([ops.SrcView(xn)], wp, (H, H), N, [(out, 0, Co, 0, 1, 0, 0)], ktap=3, pad=1, groups=2, stats=stats)
-        ref = F.conv2d(x, w, None, padding=1)
-        got = out.float().cpu().permute(0, 3, 1, 2)
-        e = float((got - ref).norm() / ref.norm())
-        s = stats.sum(1).cpu()
-        blk = got[:4]
-        ok = torch.allclose(s[0, :, 0], blk.sum((0, 2, 3)), rtol=2e-3, atol=1.0)
-        print("REL", e, ok)
-        assert e < 4e-3 and ok
-    """ % ROOT_DIR)
-    env = dict(os.environ, UCLSTM_FWD_SHAPE2="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
-    print(r.stdout[-500:], r.stderr[-1500:])
-    assert r.returncode == 0
-
-
 def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path):
     """The persistent 64-channel kernel accumulates in the same order as the generic one (taps 0..8, two 32-channel halves
     each): outputs must be bit-identical, the per-group statistics equal up to f32 summation order.  The generic kernel

@@ -45,9 +45,9 @@ struct Derived {
     uint32_t wbytes;     // panel bytes
 };
 
-// Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64);
-//                     2 = 128 x 256, waves 2x4 = 512 threads, one block per CU (large layers: 25 % less L2->LDS
-//                         traffic per flop than shape 0)
+// Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64).
+// (A 128 x 256 / 512-thread shape with a 3-stage ring and counted vmcnt measured 5-12 % slower on every layer and was
+// removed: profiles/round1_notes.md.)
 template <int SHP>
 struct Shape {
     static constexpr int WN = SHP == 1 ? 1 : 2;  // waves along panel rows
@@ -61,8 +61,8 @@ struct Shape {
     static constexpr int XBYTES = TBM * BK * 2;
     static constexpr int WBYTES = TBN * BK * 2;
     static constexpr int STAGE = XBYTES + WBYTES;
-    static constexpr int STAGES = SHP == 2 ? 3 : 2;
-    static constexpr int SMEM = STAGES * STAGE;  // 64 KiB / 80 KiB / 144 KiB
+    static constexpr int STAGES = 2;
+    static constexpr int SMEM = STAGES * STAGE;  // 64 KiB / 80 KiB
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
@@ -262,36 +262,15 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     };
 
     const int nsteps = kstep_end - kstep_begin;      // >= 1 by construction of ksplit
-    if constexpr (SH::STAGES == 3) {
-        // ---- 3-stage ring (512-thread shape, one block per CU): the DMA of steps s+1 and s+2 stays in flight ACROSS the
-        // barrier.  Per step: wait until this wave's DMA of stage s has landed (counted vmcnt leaves the younger group in
-        // flight), raw s_barrier (now every wave's part of stage s is in LDS and every wave has finished reading stage
-        // s-1 == s+2 mod 3), refill that stage, compute.  No __syncthreads() here: its fence would drain vmcnt to 0.
-        issue_loads(0);
-        if (nsteps > 1) issue_loads(1);
-        int cur = 0;
-        for (int step = 0; step < nsteps; ++step) {
-            if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XR + WR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int nxt = cur == 0 ? 2 : cur - 1;            // (cur + 2) % 3
-            if (step + 2 < nsteps) issue_loads(nxt);
-            step_body(cur, std::false_type{});
-            cur = cur == 2 ? 0 : cur + 1;
-        }
-        __syncthreads();                                       // all fragment reads done before the epilogue reuses LDS
-    } else {
-        // ---- 2-stage: DMA of step s+1 is in flight while step s computes; __syncthreads() drains it (vmcnt(0)) ----
-        issue_loads(0);
-        __syncthreads();
-        for (int step = 0; step + 1 < nsteps; ++step) {
-            step_body(step & 1, std::true_type{});
-            __syncthreads();
-        }
-        step_body((nsteps - 1) & 1, std::false_type{});
+    // ---- 2-stage: DMA of step s+1 is in flight while step s computes; __syncthreads() drains it (vmcnt(0)) ----
+    issue_loads(0);
+    __syncthreads();
+    for (int step = 0; step + 1 < nsteps; ++step) {
+        step_body(step & 1, std::true_type{});
         __syncthreads();
     }
+    step_body((nsteps - 1) & 1, std::false_type{});
+    __syncthreads();
 
     // ---- epilogue ----
     if constexpr (EPI == UCLSTM_EPI_LSTM) {
@@ -747,18 +726,10 @@ bool src_ok(const uclstm_src& s) {
 }
 
 // Block shape for a launch (also fixes the row count of the BatchNorm partial-sum buffer, so it depends only on what
-// uclstm_igemm_tiles_per_group is told): narrow panels -> 64x256; large plain convolutions -> 128x256; else 128x128.
-inline int pick_shape(int N, int64_t mg, int groups, int epi) {
+// uclstm_igemm_tiles_per_group is told): narrow panels -> 64x256, else 128x128.
+inline int pick_shape(int N, int64_t /*mg*/, int /*groups*/, int epi) {
     if (epi == UCLSTM_EPI_LSTM) return 0;
-    if (N <= 64) return 1;
-    if (epi != UCLSTM_EPI_STORE) return 0;
-    // Shape 2 (128x256, 512 threads, 3-stage ring with counted vmcnt) is correct but measured 5-12 % SLOWER than shape 0
-    // on every layer of the benchmark model (profiles/round1_notes.md): with 64-wide K-steps the kernels are bound by the
-    // per-CU global->LDS intake (~50 GB/s/CU = 64 flop/B at 128x128), and a 1.33x fatter tile does not pay for an 8-wave
-    // barrier.  It stays compiled as the skeleton of the 256x256 tile planned next; UCLSTM_FWD_SHAPE2=1 selects it.
-    static const bool want2 = [] { const char* e = getenv("UCLSTM_FWD_SHAPE2"); return e && e[0] == '1'; }();
-    const int64_t tiles128 = ((mg + 127) / 128) * groups * ((N + 127) / 128);
-    return (want2 && mg >= 256 && tiles128 >= 1024) ? 2 : 0;
+    return N <= 64 ? 1 : 0;
 }
 inline int shape_pixels(int shp) { return shp == 0 ? 128 : 256; }
 inline int shape_rows(int shp) { return shp == 1 ? 64 : 128; }
@@ -878,6 +849,5 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
     if (d.epi == UCLSTM_EPI_ATOMIC) return shp == 1 ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 0>(d, dv, nblk, st);
     if (shp == 1) return launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st);
-    if (shp == 2) return launch<UCLSTM_EPI_STORE, 2>(d, dv, nblk, st);
     return launch<UCLSTM_EPI_STORE, 0>(d, dv, nblk, st);
 }
