@@ -4,6 +4,7 @@
 // gate-interleaved ConvLSTM panel, tap-major ConvTranspose panels and the pre-gathered first
 // layer.  Run once per optimiser step per weight; memory-bound, trivially parallel.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -109,6 +110,144 @@ __global__ void unpack_kernel(const uclstm_pack_desc d, const PackDiv dv, const 
     }
 }
 
+// ---- LDS-transposing kernels (the two layout families that hold 95 % of the weights) --------------------------------
+// The per-element kernels above gather with a 36-byte stride (tap is the innermost dimension of OIHW weights, the panel's
+// K axis is tap-major): 18 cache lines per wave load, ~1.3 TB/s.  Here the reference-layout side is always touched in
+// long contiguous runs and the permutation happens in LDS.
+//
+// "Row" family (k_mode IDENTITY, stride_k == taps, stride_tap == 1: forward conv / ConvLSTM panels, every weight-gradient
+// unpack, ConvTranspose input-gradient panels): for one panel row the (channel, tap) block of a source is ONE contiguous
+// run of channels*taps floats.  Block = (panel row, source, 256-channel chunk).
+template <int TAPS, bool UNPACK>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
+                                                        bf16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
+                                                        float* __restrict__ grad, int accumulate, int chunks0) {
+    __shared__ float buf[256 * TAPS];
+    const int n = blockIdx.y;
+    const int s = (int)blockIdx.x >= chunks0 ? 1 : 0;
+    const int c0 = ((int)blockIdx.x - (s ? chunks0 : 0)) * 256;
+    const int seg = s ? d.kseg[1] : d.kseg[0];
+    const int per_tap = d.kseg[0] + d.kseg[1];
+    int n_ent, tapn;
+    const bool ok_n = decode_n(d, dv, n, n_ent, tapn);
+    int nval = (s ? d.cvalid[1] : d.cvalid[0]) - c0;
+    nval = nval < 0 ? 0 : (nval > 256 ? 256 : nval);
+    const int count = ok_n ? nval * TAPS : 0;
+    const int64_t roff = (int64_t)n_ent * d.stride_n + (int64_t)tapn * d.stride_ntap + (int64_t)((s ? d.choff[1] : d.choff[0]) + c0) * TAPS;
+    const int cl = threadIdx.x;
+    const bool col = c0 + cl < seg;                                   // a panel column of this chunk (valid or padding)
+    const int64_t pbase = (int64_t)n * d.Ktot + (s ? d.kseg[0] : 0) + c0 + cl;
+    if constexpr (!UNPACK) {
+        {   // count <= 256*TAPS: exactly TAPS strided passes, all loads issued before the first LDS store
+            float v[TAPS];
+#pragma unroll
+            for (int i = 0; i < TAPS; ++i) {
+                const int e = i * 256 + threadIdx.x;
+                v[i] = e < count ? w[roff + e] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TAPS; ++i) {
+                const int e = i * 256 + threadIdx.x;
+                if (e < count) buf[e] = v[i];
+            }
+        }
+        __syncthreads();
+        if (col) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int ts = d.tap_flip ? TAPS - 1 - t : t;
+                wp[pbase + (int64_t)t * per_tap] = f32_to_bf16((ok_n && cl < nval) ? buf[cl * TAPS + ts] : 0.f);
+            }
+        }
+    } else {
+        if (count == 0) return;
+        if (cl < nval) {
+            float v[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[t] = dwp[pbase + (int64_t)t * per_tap];
+            for (int sl = 1; sl < nslab; ++sl) {          // TAPS independent loads per slab
+                const float* ps = dwp + sl * slab + pbase;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) v[t] += ps[(int64_t)t * per_tap];
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) buf[cl * TAPS + (d.tap_flip ? TAPS - 1 - t : t)] = v[t];
+        }
+        __syncthreads();
+        float g[TAPS];
+#pragma unroll
+        for (int i = 0; i < TAPS; ++i) {
+            const int e = i * 256 + threadIdx.x;
+            g[i] = (accumulate && e < count) ? grad[roff + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TAPS; ++i) {
+            const int e = i * 256 + threadIdx.x;
+            if (e < count) grad[roff + e] = g[i] + buf[e];
+        }
+    }
+}
+
+// "Transposed" family (n_mode IDENTITY, stride_n == taps, stride_tap == 1: conv / ConvLSTM input-gradient panels; the panel
+// row is the INPUT channel, the K column an output channel or gate channel): for one K column the (row, tap) block of 16
+// consecutive panel rows is one contiguous run of 16*taps floats.  Block = 16 panel rows x 64 K columns.
+template <int TAPS>
+__global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
+                                                              bf16* __restrict__ wp) {
+    constexpr int RUN = 16 * TAPS;
+    constexpr int PITCH = RUN + 1;                                    // odd: the column-strided LDS reads are conflict-free
+    __shared__ float buf[64 * PITCH];
+    __shared__ int64_t kbase[64];
+    const int kc0 = blockIdx.x * 64;
+    const int n0 = blockIdx.y * 16;
+    const int per_tap = d.kseg[0] + d.kseg[1];
+    if (threadIdx.x < 64) {
+        const int c = kc0 + threadIdx.x;                              // single source (nsrc == 1 in this family)
+        int64_t kb = -1;
+        if (d.k_mode == UCLSTM_KMODE_IDENTITY) {
+            if (c < d.cvalid[0]) kb = (int64_t)(d.choff[0] + c) * d.stride_k;
+        } else {
+            const int gate = (int)fdiv((uint32_t)c, dv.k_hdp);
+            const int hc = c - gate * d.k_hdp;
+            if (gate < 4 && hc < d.k_hd) kb = (int64_t)(d.choff[0] + gate * d.k_hd + hc) * d.stride_k;
+        }
+        kbase[threadIdx.x] = kb;
+    }
+    __syncthreads();
+    int nrow = d.n_valid - n0;
+    nrow = nrow < 0 ? 0 : (nrow > 16 ? 16 : nrow);
+    const int run = nrow * TAPS;
+    // 64*RUN / 256 = 4*TAPS passes; four loads in flight per thread
+    for (int it = 0; it < 4 * TAPS; it += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (it + u) * 256 + threadIdx.x;
+            const int kl = e / RUN, r = e - kl * RUN;
+            const int64_t kb = kbase[kl];
+            v[u] = (r < run && kb >= 0) ? w[kb + (int64_t)n0 * TAPS + r] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (it + u) * 256 + threadIdx.x;
+            const int kl = e / RUN, r = e - kl * RUN;
+            buf[kl * PITCH + r] = v[u];
+        }
+    }
+    __syncthreads();
+    const int kl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool kok = kbase[kl] >= 0;
+    if (kc0 + kl < per_tap) {
+        for (int sgm = wv; sgm < RUN; sgm += 4) {
+            const int nl = sgm / TAPS, t = sgm - nl * TAPS;
+            if (n0 + nl >= d.N) break;
+            const int ts = d.tap_flip ? TAPS - 1 - t : t;
+            const float v = (kok && nl < nrow) ? buf[kl * PITCH + nl * TAPS + ts] : 0.f;
+            wp[(int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + kl] = f32_to_bf16(v);
+        }
+    }
+}
+
 __global__ void pack_bias_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ b, float* __restrict__ bp) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= d.N) return;
@@ -135,8 +274,40 @@ int grid_for(int64_t total) {
 
 }  // namespace
 
+namespace {
+inline bool staged_off() {
+    static const bool off = [] { const char* e = getenv("UCLSTM_PACK_GENERIC"); return e && e[0] == '1'; }();
+    return off;
+}
+inline bool rows_family(const uclstm_pack_desc& d) {
+    return !staged_off() && d.k_mode == UCLSTM_KMODE_IDENTITY && d.stride_tap == 1 && d.stride_k == d.taps && (d.taps == 9 || d.taps == 4) &&
+           d.N <= 65535;
+}
+inline bool transposed_family(const uclstm_pack_desc& d) {
+    return !staged_off() && d.n_mode == UCLSTM_NMODE_IDENTITY && d.nsrc == 1 && d.stride_tap == 1 && d.stride_n == d.taps &&
+           (d.taps == 9 || d.taps == 4) && (d.k_mode == UCLSTM_KMODE_IDENTITY || d.k_mode == UCLSTM_KMODE_GATES) && (d.N + 15) / 16 <= 65535;
+}
+}  // namespace
+
 extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream) {
     if (!desc_ok(d) || !w || !wp) return UCLSTM_E_BADARG;
+    if (rows_family(*d)) {
+        const int ch0 = (d->kseg[0] + 255) / 256, ch1 = (d->kseg[1] + 255) / 256;
+        const dim3 grid(ch0 + ch1, d->N);
+        if (d->taps == 9)
+            UCLSTM_LAUNCH((pack_rows_kernel<9, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp, nullptr, 0,
+                          (int64_t)0, nullptr, 0, ch0);
+        else
+            UCLSTM_LAUNCH((pack_rows_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp, nullptr, 0,
+                          (int64_t)0, nullptr, 0, ch0);
+        return UCLSTM_OK;
+    }
+    if (transposed_family(*d)) {
+        const dim3 grid((d->kseg[0] + d->kseg[1] + 63) / 64, (d->N + 15) / 16);
+        if (d->taps == 9) UCLSTM_LAUNCH(pack_transposed_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
+        else UCLSTM_LAUNCH(pack_transposed_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
+        return UCLSTM_OK;
+    }
     UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
     return UCLSTM_OK;
 }
@@ -144,6 +315,17 @@ extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w
 extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab, int64_t slab, float* grad,
                                        int32_t accumulate, void* stream) {
     if (!desc_ok(d) || !dwp || !grad || nslab < 1 || (nslab > 1 && slab < (int64_t)d->N * d->Ktot)) return UCLSTM_E_BADARG;
+    if (rows_family(*d) && nslab <= 64) {
+        const int ch0 = (d->kseg[0] + 255) / 256, ch1 = (d->kseg[1] + 255) / 256;
+        const dim3 grid(ch0 + ch1, d->N);
+        if (d->taps == 9)
+            UCLSTM_LAUNCH((pack_rows_kernel<9, true>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), nullptr, nullptr, dwp, nslab,
+                          slab, grad, accumulate, ch0);
+        else
+            UCLSTM_LAUNCH((pack_rows_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), nullptr, nullptr, dwp, nslab,
+                          slab, grad, accumulate, ch0);
+        return UCLSTM_OK;
+    }
     // few elements, many slabs: spread the slabs over grid.y (atomic accumulate) until the launch has ~1024 blocks
     const int gx = grid_for((int64_t)d->N * d->Ktot);
     int gy = 1;
