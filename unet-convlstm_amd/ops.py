@@ -417,10 +417,11 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
 class ZeroArena:
     """Bump allocator over one f32 buffer that is zero-filled ONCE per training step.
 
-    Every weight-gradient GEMM accumulates into a zeroed f32 panel; allocating each with ``torch.zeros`` costs one
-    ~6 us fill launch per weight (~25 per step).  ``engine.train_step`` calls ``reset()`` once, which zero-fills
-    last step's demand in a single memset; ``take`` then hands out slices.  Outside a step (tests, ad-hoc calls) or
-    when demand grows, ``take`` falls back to ``torch.zeros``."""
+    The BatchNorm backward reductions accumulate (f32 atomics) into zeroed per-(group, channel) sums; allocating each
+    with ``torch.zeros`` costs one ~6 us fill launch per layer.  ``engine.train_step`` calls ``reset()`` once, which
+    zero-fills last step's demand in a single memset; ``take`` then hands out slices.  Outside a step (tests, ad-hoc
+    calls) or when demand grows, ``take`` falls back to ``torch.zeros``.  (Weight-gradient and split-K accumulators
+    used to live here too; they are per-range slabs now and need no zeroing.)"""
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
