@@ -195,8 +195,9 @@ template <int TAPS>
 __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
                                                               bf16* __restrict__ wp) {
     constexpr int RUN = 16 * TAPS;
-    constexpr int PITCH = RUN + 1;                                    // odd: the column-strided LDS reads are conflict-free
-    __shared__ float buf[64 * PITCH];
+    constexpr int PITCH = RUN + 2;                                    // in bf16: 73 dwords per column, odd -> conflict-free reads
+    __shared__ bf16 buf[64 * PITCH];                                  // 18 KiB (already rounded: the panel is bf16), small enough
+                                                                      // to share a CU with a 128-KiB weight-gradient block
     __shared__ int64_t kbase[64];
     const int kc0 = blockIdx.x * 64;
     const int n0 = blockIdx.y * 16;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
         for (int u = 0; u < 4; ++u) {
             const int e = (it + u) * 256 + threadIdx.x;
             const int kl = e / RUN, r = e - kl * RUN;
-            buf[kl * PITCH + r] = v[u];
+            buf[kl * PITCH + r] = f32_to_bf16(v[u]);
         }
     }
     __syncthreads();
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
             const int nl = sgm / TAPS, t = sgm - nl * TAPS;
             if (n0 + nl >= d.N) break;
             const int ts = d.tap_flip ? TAPS - 1 - t : t;
-            const float v = (kok && nl < nrow) ? buf[kl * PITCH + nl * TAPS + ts] : 0.f;
-            wp[(int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + kl] = f32_to_bf16(v);
+            const bf16 v = (kok && nl < nrow) ? buf[kl * PITCH + nl * TAPS + ts] : f32_to_bf16(0.f);
+            wp[(int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + kl] = v;
         }
     }
 }
