@@ -126,7 +126,8 @@ def test_conv3x3_forward(N, C0, C1, Co, H, W):
     assert pad_is_zero(out, Co)
 
 
-def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path):
+@pytest.mark.parametrize("W", [64, 128, 320])
+def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path, W):
     """The persistent 64-channel kernel accumulates in the same order as the generic one (taps 0..8, two 32-channel halves
     each): outputs must be bit-identical, the per-group statistics equal up to f32 summation order.  The generic kernel
     runs in a subprocess with UCLSTM_FWD_C64=0 (the switch is read once per process)."""
@@ -137,7 +138,7 @@ def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path):
         import unet_convlstm_amd as U
         from unet_convlstm_amd import ops
         torch.manual_seed(21)
-        N, H, W, groups = 6, 12, 64, 3
+        N, H, W, groups = 6, 12, int(sys.argv[2]), 3
         xn = (torch.randn(N, H, W, 64) * 0.7).to(torch.bfloat16).cuda()
         w = (torch.randn(64, 64, 3, 3) * 0.1).cuda()
         b = (torch.randn(64) * 0.3).cuda()
@@ -152,7 +153,7 @@ def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path):
     res = {}
     for tag, val in (("ring", "1"), ("generic", "0")):
         f = str(tmp_path / (tag + ".pt"))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, UCLSTM_FWD_C64=val), capture_output=True, text=True,
+        r = subprocess.run([sys.executable, "-c", code, f, str(W)], env=dict(os.environ, UCLSTM_FWD_C64=val), capture_output=True, text=True,
                            timeout=240)
         assert r.returncode == 0, r.stderr[-1500:]
         res[tag] = torch.load(f)
@@ -254,6 +255,8 @@ def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
     (4, 64, 64, 8, 64, 2),
     (6, 64, 64, 4, 64, 2),
     (2, 64, 64, 64, 64, 2),
+    (8, 64, 64, 8, 128, 2),       # two 64-pixel column strips: real halo columns between them
+    (6, 64, 64, 4, 192, 1),
 ])
 def test_conv_bn_relu_train_fwd_bwd_two_groups(N, Ci, Co, H, W, groups):
     torch.manual_seed(4)
@@ -290,7 +293,7 @@ def test_conv_bn_relu_train_fwd_bwd_two_groups(N, Ci, Co, H, W, groups):
     # K = 576 sums of bf16-rounded dz: the largest single dx element and the (cancelling) dbeta sums sit a little higher on
     # the 64-channel cases; the generic kernel gives the same figures to four digits (UCLSTM_FWD_C64=0)
     big = Ci >= 64
-    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "conv+bn+relu dx", l2=1.5e-2, mx=1e-1 if big else 5e-2)
+    check_bf16(from_nhwc(xg.grad, Ci), xr.grad, "conv+bn+relu dx", l2=1.5e-2, mx=1.5e-1 if big else 5e-2)
     check_f32(wg.grad.cpu(), wr.grad, "conv+bn+relu dW", l2=1.5e-2)
     check_f32(gg.grad.cpu(), gr.grad, "dgamma", l2=1e-2)
     check_f32(bg.grad.cpu(), br.grad, "dbeta", l2=2e-2 if big else 1e-2)

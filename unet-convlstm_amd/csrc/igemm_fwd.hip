@@ -428,8 +428,8 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 3x3 / pad 1 convolution with C_in = C_out = 64 on 64-pixel-wide images (the full-resolution level of the UNet at the
-// 64x64 configurations: 2.6 M pixels, K = 576 -- nine K-steps per tile, where the generic kernel spends as long in its
+// 3x3 / pad 1 convolution with C_in = C_out = 64 on images whose width is a multiple of 64 (the full-resolution level of
+// the UNet; at the 64x64 configurations: 2.6 M pixels, K = 576 -- nine K-steps per tile, where the generic kernel spends as long in its
 // prologue/epilogue as in the loop and re-stages every activation row nine times through the LDS-DMA path: 545 TFLOP/s).
 // Persistent blocks, one per CU, 4 waves:
 //   * the whole weight panel (9 taps x 64 rows x 128 B = 72 KiB) stays resident in LDS;
@@ -506,21 +506,42 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         const int sc = (lane & 7) ^ ((xp + 1) & 7);
         rvoff[i] = (uint32_t)(2 * (xp * 64 + sc * 8));
     }
-    const uint32_t row_bytes = (uint32_t)(64 * 64 * 2);            // one image row
-    // cursor of the next virtual row to stage: (image lk, row ly in 0..H where H = the zero row), its ring slot.  Plain
+    // Images wider than 64 pixels are cut into 64-pixel column STRIPS; a "sequence" is one strip of one image (index
+    // image*strips + strip), tiles walk down a sequence.  With more than one strip the halo columns are real pixels of the
+    // neighbouring strip (or zero at the image border): waves 0 and 1 re-stage them with every row (8 pixels each, of which
+    // the ring keeps one: the DMA granule is a whole wave).
+    const int strips = d.W >> 6;
+    const int n_seq = d.n_img * strips;
+    const uint32_t px_bytes = 128u;                                  // 64 channels
+    // cursor of the next virtual row to stage: (sequence lk, row ly in 0..H where H = the zero row), its ring slot.  Plain
     // locals advanced by a macro: as by-reference lambda captures they ended up in scratch memory.
     int lk = 0, ly = 0, lslot = 0, loaded = -2;
+    int limg = 0, lstrip = 0;
 #define C64_ISSUE_NEXT_ROW()                                                                                              \
     {                                                                                                                     \
-        const bool zero_ = ly == H || lk < 0 || lk >= d.n_img;                                                            \
-        const uint32_t soff_ = zero_ ? 0u : (uint32_t)(lk * H + ly) * row_bytes;                                          \
+        const bool zero_ = ly == H || lk < 0 || lk >= n_seq;                                                              \
+        const uint32_t soff_ = zero_ ? 0u : (uint32_t)((limg * H + ly) * d.W + lstrip * 64) * px_bytes;                   \
         unsigned char* dst_ = Ring + lslot * C64_ROW + 128;                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + wave * 1024), 16, zero_ ? OOB : rvoff[0], soff_, 0, 0);       \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + (wave + 4) * 1024), 16, zero_ ? OOB : rvoff[1], soff_, 0, 0); \
+        if (strips > 1 && wave < 2) {                                                                                     \
+            const bool ok_ = !zero_ && (wave == 0 ? lstrip > 0 : lstrip < strips - 1);                                    \
+            const uint32_t hs_ = ok_ ? (wave == 0 ? soff_ - px_bytes : soff_ + 64u * px_bytes) : 0u;                      \
+            unsigned char* hd_ = Ring + lslot * C64_ROW + (wave == 0 ? 0 : 65 * 128);                                     \
+            if (lane < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)hd_, 16, ok_ ? halo_voff : OOB, hs_, 0, 0);          \
+        }                                                                                                                 \
         ++loaded;                                                                                                         \
         lslot = lslot == C64_SLOTS - 1 ? 0 : lslot + 1;                                                                   \
-        if (ly == H) { ly = 0; ++lk; } else { ++ly; }                                                                     \
+        if (ly == H) {                                                                                                    \
+            ly = 0;                                                                                                       \
+            ++lk;                                                                                                         \
+            if (++lstrip == strips) { lstrip = 0; ++limg; }                                                               \
+        } else {                                                                                                          \
+            ++ly;                                                                                                         \
+        }                                                                                                                 \
     }
+    // halo pixel: position 0 (left, wave 0) or 65 (right, wave 1) holds chunk (lane&7) ^ (position & 7)
+    const uint32_t halo_voff = (uint32_t)(2 * ((((lane & 7) ^ (wave == 0 ? 0 : 1)) & 7) * 8));
 
     // fragment read offsets
     int xoff[4][3][2];          // [b][dx][ksub]: inside a ring row
@@ -565,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         const int v0 = k * (H + 1) + 4 * tr;
         if (tt == t_begin) {      // cursor at virtual row v0 - 1
             const int v = v0 - 1;
-            if (v < 0) { lk = -1; ly = H; } else { lk = v / (H + 1); ly = v - lk * (H + 1); }
+            if (v < 0) { lk = -1; ly = H; limg = 0; lstrip = -1; } else { lk = v / (H + 1); ly = v - lk * (H + 1); limg = lk / strips; lstrip = lk - limg * strips; }
             lslot = (v + 1) % C64_SLOTS;
             loaded = v - 1;
         }
@@ -622,7 +643,8 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
 
         // ---- epilogue from registers: wave = image row y, lane = (pixel b*16 + l15, channels a*16 + lq*4 .. +3) ----
         const int y = 4 * tr + wave;
-        bf16* orow = (bf16*)sg.ptr + ((long)(k * H + y) * 64) * (long)sg.C + sg.c_off;
+        const int img = k / strips, strip = k - img * strips;
+        bf16* orow = (bf16*)sg.ptr + ((long)(img * H + y) * d.W + strip * 64) * (long)sg.C + sg.c_off;
         float s1[4][4], s2[4][4];
         Pack8 ov[4][4];           // [a][b]: this lane's 4 channels of pixel b*16 + l15, bf16
 #pragma unroll
@@ -711,14 +733,14 @@ inline bool c64_ok(const uclstm_igemm_desc& d) {
     static const bool off = [] { const char* e = getenv("UCLSTM_FWD_C64"); return e && e[0] == '0'; }();
     if (off || d.epi != UCLSTM_EPI_STORE || d.nsrc != 1 || d.ktap != 3 || d.pad != 1 || d.scale != 1) return false;
     const uclstm_src& S = d.src[0];
-    if (S.C != 64 || d.N != 64 || d.Ktot != 576 || d.W != 64 || (d.H & 3) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
+    if (S.C != 64 || d.N != 64 || d.Ktot != 576 || (d.W & 63) || (d.H & 3) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
     if (d.nseg != 1) return false;
     const uclstm_seg& g = d.seg[0];
     if (g.scale != 1 || g.oy || g.ox || g.Hd != d.H || g.Wd != d.W || g.n_begin != 0 || g.n_end > 64 || (g.n_end % 8) || (g.C % 8) ||
         (g.c_off % 8))
         return false;
     if ((int64_t)d.n_img * d.H * d.W * 64 * 2 >= ((int64_t)1 << 31) - (1 << 22)) return false;
-    if ((int64_t)d.n_img * (d.H + 1) >= ((int64_t)1 << 30)) return false;
+    if ((int64_t)d.n_img * (d.W / 64) * (d.H + 1) >= ((int64_t)1 << 30)) return false;
     return true;
 }
 
@@ -839,7 +861,7 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
             (void)hipFuncSetAttribute((const void*)igemm_fwd_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_SMEM);
             attr64 = true;
         }
-        const int tiles_total = d.n_img * (d.H / 4);
+        const int tiles_total = d.n_img * (d.W / 64) * (d.H / 4);
         const int blocks = tiles_total < 256 ? tiles_total : 256;
         const int per = (tiles_total + blocks - 1) / blocks;
         const int grid = (tiles_total + per - 1) / per;
