@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 2
+#define UCLSTM_ABI_VERSION 3
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -187,9 +187,12 @@ int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group
 /* a = relu(z*scale[g] + shift[g]),  g = pixel / pixels_per_group;  z, a bf16 [pixels][Cp]. */
 int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift,
                              int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
-/* Backward pass 1: sums[g][c] = (sum g_, sum g_*xhat), g_ = dA * [scale*z+shift > 0]; sums must be zeroed. */
+/* Backward pass 1: sums[g][c] = (sum g_, sum g_*xhat), g_ = dA * [scale*z+shift > 0].  Deterministic (no atomics): every
+ * block writes its partial sums into `partials` ([uclstm_bn_bwd_reduce_rows()][Cp][2] floats, caller-allocated, need not
+ * be initialised), a second kernel adds them in a fixed order into `sums` ([groups][Cp][2], overwritten). */
+int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_group);
 int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift,
-                             const float* mean, const float* rstd, float* sums,
+                             const float* mean, const float* rstd, float* partials, float* sums,
                              int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
 /* Backward pass 2: dz = scale*(g_ - s1/n - xhat*s2/n)  (bf16). */
 int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, const float* shift,

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -88,7 +88,8 @@ _PROTOS = {
     "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],
     "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     "uclstm_bn_apply_relu": [_P, _P, _P, _P, _L, _L, _I, _P],
-    "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
+    "uclstm_bn_bwd_reduce_rows": [_L, _L],
+    "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_param_grads": [_P, _I, _I, _I, _P, _P, _I, _P],
     "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
@@ -114,7 +115,7 @@ _PROTOS = {
     "uclstm_build_arch": [],
     "uclstm_last_error_string": [],
 }
-_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_char_p}
+_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64}
 
 
 def header_symbols() -> list[str]:

@@ -4,6 +4,7 @@
 // over pixels keep a fixed channel chunk per thread, reduce across the block in LDS and finish with
 // one f32 atomic per (block, channel).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -147,10 +148,12 @@ static ColGeom col_geom(int Cp) {
     return g;
 }
 
-// sums[g][c][0..1] += (sum g_, sum g_*xhat)
+// partials[g*blocks_per_group + bi][c][0..1] = this block's (sum g_, sum g_*xhat).  No atomics: the run-to-run order of f32
+// atomic adds here changed the whole gradient by ~1e-3 (the sums feed dz, and BatchNorm backward at random init amplifies
+// 1e-7 perturbations through its bf16 roundings layer after layer); bn_bwd_sum_kernel adds the rows in a fixed order.
 __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, float* __restrict__ sums, int64_t ppg, int Cp, ColGeom cg,
+                                     const float* __restrict__ rstd, float* __restrict__ partials, int64_t ppg, int Cp, ColGeom cg,
                                      int blocks_per_group, int64_t pix_per_block) {
     extern __shared__ float red[];     // [rows][cpc*16]
     const int g = blockIdx.x / blocks_per_group;
@@ -213,7 +216,7 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
             float t = 0.f;
             for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
             const int ch = (cbase * 8) + (j >> 1);
-            if (ch < Cp) atomicAdd(sums + ((long)g * Cp + ch) * 2 + (j & 1), t);
+            if (ch < Cp) partials[((long)blockIdx.x * Cp + ch) * 2 + (j & 1)] = t;
         }
         __syncthreads();
     }
@@ -223,6 +226,27 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
 // range of ONE group, a thread one 16-byte channel chunk of every `rows`-th pixel row, so
 //     dz = sc*(g_ - s1/n - xhat*s2/n) = sc*g_ + k1*z + k0,   k1 = -sc*rs*s2/n,  k0 = -sc*s1/n - k1*mu
 // costs two loads, one store and a handful of FMAs per chunk (the generic kernel re-loads ten float4 of constants per chunk).
+// Fixed-order sum of the partial rows: block = (group, 32 consecutive (channel, j) entries), 8 row lanes each adding every
+// 8th row in f64, then lane 0 adds the 8 lane sums in order.
+__global__ __launch_bounds__(256) void bn_bwd_sum_kernel(const float* __restrict__ partials, float* __restrict__ sums, int blocks_per_group,
+                                                         int Cp) {
+    __shared__ double red[8][32];
+    const int g = blockIdx.y;
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31);          // entry (c*2 + j) of the group
+    const int lane = threadIdx.x >> 5;
+    double t = 0.0;
+    if (e < Cp * 2)
+        for (int b = lane; b < blocks_per_group; b += 8) t += (double)partials[((long)(g * blocks_per_group + b) * Cp) * 2 + e];
+    red[lane][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (lane == 0 && e < Cp * 2) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+        sums[(long)g * Cp * 2 + e] = (float)s;
+    }
+}
+
 __global__ void bn_bwd_apply_cols_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                          const float* __restrict__ rstd, const float* __restrict__ sums, uint4* __restrict__ dz,
@@ -779,22 +803,35 @@ extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* sca
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
-                                        const float* rstd, float* sums, int64_t pixels, int64_t pixels_per_group, int32_t Cp,
-                                        void* stream) {
-    if (!aligned16(z) || !aligned16(da) || !scale || !shift || !mean || !rstd || !sums || pixels <= 0 || pixels_per_group <= 0 ||
-        (pixels % pixels_per_group) || Cp <= 0 || (Cp % 8))
-        return UCLSTM_E_BADARG;
-    const ColGeom cg = col_geom(Cp);
-    const int groups = (int)(pixels / pixels_per_group);
+namespace {
+inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
     int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
     const int cap = (4096 + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
-    if (bpg < 1) bpg = 1;
+    return bpg < 1 ? 1 : bpg;
+}
+}  // namespace
+
+extern "C" int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_group) {
+    if (pixels <= 0 || pixels_per_group <= 0 || (pixels % pixels_per_group)) return UCLSTM_E_BADARG;
+    const int groups = (int)(pixels / pixels_per_group);
+    return (int64_t)groups * bn_bwd_blocks_per_group(pixels_per_group, groups);
+}
+
+extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, float* partials, float* sums, int64_t pixels, int64_t pixels_per_group,
+                                        int32_t Cp, void* stream) {
+    if (!aligned16(z) || !aligned16(da) || !scale || !shift || !mean || !rstd || !partials || !sums || pixels <= 0 ||
+        pixels_per_group <= 0 || (pixels % pixels_per_group) || Cp <= 0 || (Cp % 8))
+        return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    const int groups = (int)(pixels / pixels_per_group);
+    const int bpg = bn_bwd_blocks_per_group(pixels_per_group, groups);
     const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
     UCLSTM_LAUNCH(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
-                       scale, shift, mean, rstd, sums, pixels_per_group, Cp, cg, bpg, ppb);
+                       scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb);
+    UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
     return UCLSTM_OK;
 }
 

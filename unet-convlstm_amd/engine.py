@@ -175,7 +175,6 @@ def train_step(model, optimizer, x, y, mask=None, use_mask=True, ddp=None, clip_
     """zero_grad -> forward -> stack -> loss -> backward -> [gradient all-reduce] -> clip(1.0) -> optimiser step
     (main.py:91-108).  Returns ``(loss, y_pred)`` as device tensors; nothing here waits for the GPU."""
     optimizer.zero_grad(set_to_none=True)
-    ops.arena(x.device).reset(x.device)      # one memset for all of this step's weight-gradient accumulators
     if ddp is not None:
         ddp.reset()
     output, _ = model(x)

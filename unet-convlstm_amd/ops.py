@@ -423,53 +423,6 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
            f"M={B * H * W} N={d.N} K={d.Ktot}")
 
 
-class ZeroArena:
-    """Bump allocator over one f32 buffer that is zero-filled ONCE per training step.
-
-    The BatchNorm backward reductions accumulate (f32 atomics) into zeroed per-(group, channel) sums; allocating each
-    with ``torch.zeros`` costs one ~6 us fill launch per layer.  ``engine.train_step`` calls ``reset()`` once, which
-    zero-fills last step's demand in a single memset; ``take`` then hands out slices.  Outside a step (tests, ad-hoc
-    calls) or when demand grows, ``take`` falls back to ``torch.zeros``.  (Weight-gradient and split-K accumulators
-    used to live here too; they are per-range slabs now and need no zeroing.)"""
-
-    def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
-        self.off = 0          # demand counted in the current step (elements)
-        self.zeroed = 0       # elements of buf known to be zero and not yet handed out
-
-    def reset(self, device) -> None:
-        need = self.off
-        self.off = 0
-        if need == 0:
-            self.zeroed = 0
-            return
-        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
-            self.buf = torch.empty(int(need * 1.05) + 1024, dtype=F32, device=device)
-        self.buf[:need].zero_()
-        self.zeroed = need
-
-    def take(self, shape, device) -> torch.Tensor:
-        n = 1
-        for s in shape:
-            n *= int(s)
-        n_al = (n + 63) // 64 * 64          # keep every slice 256-byte aligned
-        off = self.off
-        self.off += n_al
-        if self.buf is not None and self.buf.device == device and off + n_al <= self.zeroed:
-            return self.buf[off:off + n].view(*shape)
-        return torch.zeros(shape, dtype=F32, device=device)
-
-
-_ARENAS = {}
-
-
-def arena(device) -> ZeroArena:
-    key = str(device)
-    if key not in _ARENAS:
-        _ARENAS[key] = ZeroArena()
-    return _ARENAS[key]
-
-
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
                 pad: int = 0) -> torch.Tensor:
     dev = srcs[0].t.device
@@ -678,8 +631,9 @@ class ConvBNReLU(torch.autograd.Function):
         n_img, H, W, Cop = z.shape
         dev = z.device
         pixels, ppg = n_img * H * W, (n_img // groups) * H * W
-        sums = arena(dev).take((groups, Cop, 2), dev)         # zeroed once per step with the other accumulators
-        L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), pixels, ppg, Cop,
+        sums = torch.empty((groups, Cop, 2), dtype=F32, device=dev)
+        partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
+        L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
                                            _stream()), "bn_bwd_reduce")
         dz = torch.empty_like(z)
         L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), _p(dz), pixels, ppg,
