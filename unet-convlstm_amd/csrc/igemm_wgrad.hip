@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
 // the fast path above (planes of [64 pixels][64 columns], buffer-addressed zero-filling DMA, scalar-vs-constant tap
 // validity); what changes is the pipeline:
 //   * a K-tile (64 pixels) is staged as four HALF-tiles of two planes (16 KiB): dY-lo, X-lo, X-hi, dY-hi, in the order the
-//     phases consume them; every phase issues one half-tile six halves ahead (LEAD) and waits with a COUNTED vmcnt, so up
-//     to four half-tiles stay in flight across the raw s_barriers (never vmcnt(0) in the steady state);
+//     phases consume them; every phase issues one half-tile LEAD (7, or 6) halves ahead and waits with a COUNTED vmcnt, so
+//     LEAD - 2 half-tiles stay in flight across the raw s_barriers (never vmcnt(0) in the steady state);
 //   * a wave owns 128 x 64 of the tile as four 64 x 32 quadrants, one quadrant (16 MFMA) per phase; its rows/columns are
 //     interleaved over the halves so that each half is read in exactly one phase: dY-lo + X-lo in phase 0, X-hi in 1,
 //     dY-hi in 2, none in 3 -> a half is re-staged at least two phases after its last read (write-after-read safe with the
@@ -477,9 +477,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
 constexpr int P3_HALF = 2 * PLANE;            // 16 KiB
 constexpr int P3_BUF = 4 * P3_HALF;           // 64 KiB
 constexpr int P3_SMEM = 2 * P3_BUF;           // 128 KiB
-constexpr int P3_LEAD = 6;
 
-template <int NSRC>
+template <int NSRC, int P3_LEAD>
 __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgrad_desc d, const WDerived dv, const P2 p2) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -607,8 +606,13 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
 #pragma unroll
     for (int q = 0; q < P3_LEAD; ++q)
         if (q < total_halves) issue_half(q >> 2, q & 3);
-    if (total_halves >= P3_LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // in flight after a wait: LEAD - 2 half-tiles = 2*(LEAD-2) DMA instructions of this wave
+    if (total_halves >= P3_LEAD) {
+        if constexpr (P3_LEAD == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger: group 1 runs one barrier behind
     __builtin_amdgcn_s_barrier();
 
@@ -639,10 +643,14 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
             }
             if (g + P3_LEAD < total_halves) {
                 issue_half(ktile + ((p + P3_LEAD) >> 2), (p + P3_LEAD) & 3);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if constexpr (P3_LEAD == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            // LEAD 7 re-stages dY-lo ONE phase after its reads (phase 0): those reads must have retired before this barrier,
+            // because the other wave group runs a barrier behind (guide: "1 phase after when an lgkmcnt retired those reads")
+            if (P3_LEAD == 7 && p == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -846,13 +854,23 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
 
     if (big) {
         static bool attr3 = false;
+        // seven half-tiles ahead (five in flight across a barrier) is the default: +11 % on the 4096 x 18432 gradient over six
+        // (same box A/B); UCLSTM_P3_LEAD=6 selects the shallower ring
+        static const bool lead7 = [] { const char* e = getenv("UCLSTM_P3_LEAD"); return !(e && e[0] == '6'); }();
         if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
-            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<1, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_p3_kernel<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
             attr3 = true;
         }
-        if (d.nsrc == 1) UCLSTM_LAUNCH(igemm_wgrad_p3_kernel<1>, dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
-        else UCLSTM_LAUNCH(igemm_wgrad_p3_kernel<2>, dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+        if (lead7) {
+            if (d.nsrc == 1) UCLSTM_LAUNCH((igemm_wgrad_p3_kernel<1, 7>), dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+            else UCLSTM_LAUNCH((igemm_wgrad_p3_kernel<2, 7>), dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+        } else {
+            if (d.nsrc == 1) UCLSTM_LAUNCH((igemm_wgrad_p3_kernel<1, 6>), dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+            else UCLSTM_LAUNCH((igemm_wgrad_p3_kernel<2, 6>), dim3((unsigned)nblk), dim3(512), P3_SMEM, st, dd, dv, p2);
+        }
         return UCLSTM_OK;
     }
     if (fast) {
