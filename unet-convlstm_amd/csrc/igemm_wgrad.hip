@@ -469,8 +469,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
 //     LEAD - 2 half-tiles stay in flight across the raw s_barriers (never vmcnt(0) in the steady state);
 //   * a wave owns 128 x 64 of the tile as four 64 x 32 quadrants, one quadrant (16 MFMA) per phase; its rows/columns are
 //     interleaved over the halves so that each half is read in exactly one phase: dY-lo + X-lo in phase 0, X-hi in 1,
-//     dY-hi in 2, none in 3 -> a half is re-staged at least two phases after its last read (write-after-read safe with the
-//     stagger below);
+//     dY-hi in 2, none in 3 -> with LEAD 6 a half is re-staged at least two phases after its last read (write-after-read
+//     safe with the stagger below); with LEAD 7 dY-lo is re-staged ONE phase after its reads, which are therefore retired
+//     (lgkmcnt(0)) before the phase-0 barrier;
 //   * waves 4-7 run one barrier behind waves 0-3 (they share the SIMDs pairwise): one group's MFMA section overlaps the
 //     other group's LDS reads + DMA issue.
 // One block per CU (128 KiB LDS).  Used when C_out >= 256; pixel splits keep the grid a multiple of the 256 CUs.
