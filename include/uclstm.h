@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 3
+#define UCLSTM_ABI_VERSION 4
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -131,6 +131,9 @@ typedef struct {
     float* dwp;
     int32_t splits;
     int32_t accumulate;
+    int32_t overlapped; /* != 0: the launch runs beside other GEMMs (side stream): the automatic range count (splits = 0) then
+                         * minimises interference (few slabs, grid below the CU count) instead of the kernel's own duration */
+    int32_t reserved_;
     int64_t slab;     /* 0: pixel ranges ADD into dwp with f32 atomics (dwp zeroed by the caller).  > 0 (>= N*Ktot): range r
                        * STORES its partial panel to dwp + r*slab (floats), nothing needs zeroing, and uclstm_unpack_wgrad adds
                        * the uclstm_igemm_wgrad_splits() slabs (float atomics ~1.3 TB/s, stores ~6 TB/s on MI355X). */

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -61,7 +61,8 @@ class WgradDesc(C.Structure):
                 ("src", Src * 2),
                 ("N", C.c_int32), ("Ktot", C.c_int32),
                 ("nseg", C.c_int32), ("seg", Seg * 4),
-                ("dwp", C.c_void_p), ("splits", C.c_int32), ("accumulate", C.c_int32), ("slab", C.c_int64)]
+                ("dwp", C.c_void_p), ("splits", C.c_int32), ("accumulate", C.c_int32), ("overlapped", C.c_int32), ("reserved_", C.c_int32),
+                ("slab", C.c_int64)]
 
 
 class PackDesc(C.Structure):

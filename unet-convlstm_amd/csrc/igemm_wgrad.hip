@@ -713,17 +713,35 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
 #endif
 }
 
-// Splits for the one-block-per-CU kernel.  These launches run on the side stream next to the input-gradient chain; what
-// the step needs from them is not a short kernel but little interference: few slabs (each is written here and read back by
-// the unpack) and a grid that does not have to cover every CU.  Same-box sweeps of the step time: the plan that fills whole
-// rounds of 256 CUs (fastest kernels in isolation) gave 16.49 k frames/s, 0.35x its split counts 16.74 k, 0.25x 16.67 k.
-// Rule: the fewest splits that still give UCLSTM_P3_MIN_BLOCKS (default 128) blocks, at least 8 stages per block.
-int auto_splits256(int64_t tiles, int64_t stages, bool /*slabs*/, int64_t /*panel_elems*/) {
-    static const int min_blocks = [] { const char* e = getenv("UCLSTM_P3_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
-    int64_t s = (min_blocks + tiles - 1) / tiles;
+// Splits for the one-block-per-CU kernel, two regimes (uclstm_wgrad_desc::overlapped):
+//  * stand-alone launch: whole rounds of the 256 CUs, every extra slab priced (written here, read back by the unpack);
+//  * launch that runs on a side stream next to the input-gradient chain: what the step needs from it is not a short kernel
+//    but little interference -- few slabs and a grid that does not have to cover every CU (a 128-KiB block excludes every
+//    64-KiB GEMM block from its CU).  Same-box sweeps of the STEP time: the stand-alone plan gave 16.49 k frames/s, 0.35x its
+//    split counts 16.74 k.  Rule: the fewest splits that still give UCLSTM_P3_MIN_BLOCKS (default 128) blocks.
+int auto_splits256(int64_t tiles, int64_t stages, bool slabs, int64_t panel_elems, bool overlapped) {
     const int64_t smax = stages / 8 > 1 ? stages / 8 : 1;
-    if (s > smax) s = smax;
-    return (int)(s < 1 ? 1 : s);
+    if (overlapped) {
+        static const int min_blocks = [] { const char* e = getenv("UCLSTM_P3_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
+        int64_t s = (min_blocks + tiles - 1) / tiles;
+        if (s > smax) s = smax;
+        return (int)(s < 1 ? 1 : s);
+    }
+    const double slab_cost = slabs ? (double)panel_elems * 8.0 / 4e12 / 1.9e-6 : 0.0;      // see auto_splits; a stage is ~1.9 us here
+    const int64_t fixed = slabs ? 8 : 28;     // 256 KiB per block: ~50 us of float atomics vs ~11 us of stores
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int64_t s = 1; s <= smax && tiles * s <= 8192; ++s) {
+        const int64_t per = (stages + s - 1) / s;
+        const int64_t used = (stages + per - 1) / per;
+        const int64_t rounds = (tiles * used + 255) / 256;
+        const int64_t cost = rounds * (per + fixed) + (int64_t)(slab_cost * (double)used);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = (int)s;
+        }
+    }
+    return best;
 }
 
 // Pixel-range splits: minimise (rounds of the 512 resident blocks) x (stages per block + fixed cost of a block's
@@ -835,7 +853,7 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
     uclstm_wgrad_desc dd = d;
     const bool slabs = d.slab > 0;
     if (dd.splits <= 0)
-        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs, (int64_t)d.N * d.Ktot)
+        dd.splits = big ? auto_splits256((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs, (int64_t)d.N * d.Ktot, d.overlapped != 0)
                         : auto_splits((int64_t)dv.n_kt * dv.n_nt, (dv.M + TP - 1) / TP, slabs, (int64_t)d.N * d.Ktot);
     long chunk = (dv.M + dd.splits - 1) / dd.splits;
     chunk = (chunk + TP - 1) / TP * TP;

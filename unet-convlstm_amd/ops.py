@@ -276,6 +276,7 @@ def _fold_slabs(dwp: torch.Tensor) -> torch.Tensor:
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
 DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
 GRAD_SIDE_HOOKS: list = []
+_WGRAD_OVERLAPPED = False      # True while a weight-gradient GEMM is being enqueued on the side stream
 _SIDE_STREAMS = {}
 _JOIN_PENDING = set()
 
@@ -309,8 +310,13 @@ def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[to
     dev = weight.device
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
     side.wait_stream(main)                      # dz / activations produced so far are visible to the side stream
+    global _WGRAD_OVERLAPPED
     with torch.cuda.stream(side):
-        dwp = _fold_slabs(run_gemm())
+        _WGRAD_OVERLAPPED = True
+        try:
+            dwp = _fold_slabs(run_gemm())
+        finally:
+            _WGRAD_OVERLAPPED = False
         ns, st = _slabs_of(dwp)
         L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), ns, st, _p(g), 1, _stream()), "unpack_wgrad(accumulate)")
         for t in inputs:
@@ -439,6 +445,7 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     # slab mode: every pixel range stores its partial panel into its own slab (no float atomics, nothing to zero);
     # the library picks the range count for its tile shape and the 256 CUs, uclstm_unpack_wgrad adds the slabs
     d.splits, d.accumulate, d.slab = 0, 1, N * Ktot
+    d.overlapped = int(_WGRAD_OVERLAPPED)          # on the side stream: the plan that interferes least with the main stream
     splits = int(L.lib.uclstm_igemm_wgrad_splits(C.byref(d)))
     if splits < 1:
         raise L.UclstmError(f"igemm_wgrad: bad descriptor (code {splits})")
