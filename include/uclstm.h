@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 4
+#define UCLSTM_ABI_VERSION 5
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -292,6 +292,12 @@ int32_t uclstm_dataset_transform(const float* x_raw, const float* y_raw, float* 
  * d = denormalize(y_pred) - denormalize(y) (train/unet.py:316-319, asinh transform); mask may be NULL. */
 int32_t uclstm_metric_sums(const float* y_pred, const float* y, const float* mask, double* sums, int64_t n, float y_scale,
                            float trans_min, float trans_max, void* stream);
+
+/* Scheduling aid, no reference counterpart: one wavefront that busy-waits `microseconds` of the constant 100 MHz wall clock on
+ * `stream`.  The host layer uses it to find out whether two HIP streams really execute concurrently (streams that the
+ * runtime multiplexes onto the same hardware queue serialise; which streams collide changes when e.g. an RCCL
+ * communicator has created streams of its own first). */
+int32_t uclstm_stream_spin(int32_t microseconds, void* stream);
 
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -112,6 +112,7 @@ _PROTOS = {
     "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
     "uclstm_dataset_transform": [_P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _F, _F, _F, _P],
     "uclstm_metric_sums": [_P, _P, _P, _P, _L, _F, _F, _F, _P],
+    "uclstm_stream_spin": [_I, _P],
     "uclstm_abi_version": [],
     "uclstm_build_arch": [],
     "uclstm_last_error_string": [],

@@ -238,6 +238,19 @@ extern "C" int32_t uclstm_metric_sums(const float* y_pred, const float* y, const
     return UCLSTM_OK;
 }
 
+namespace {
+__global__ void stream_spin_kernel(long ticks) {
+    const long t0 = wall_clock64();                      // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+extern "C" int32_t uclstm_stream_spin(int32_t microseconds, void* stream) {
+    if (microseconds <= 0 || microseconds > 100000) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)microseconds * 100);
+    return UCLSTM_OK;
+}
+
 extern "C" int32_t uclstm_abi_version(void) { return UCLSTM_ABI_VERSION; }
 extern "C" const char* uclstm_build_arch(void) { return "gfx950"; }
 extern "C" const char* uclstm_last_error_string(void) { return hipGetErrorString((hipError_t)g_uclstm_last_hip_error); }

@@ -27,6 +27,8 @@ class FlatDDP:
             raise RuntimeError("FlatDDP: torch.distributed is not initialised")
         self.module, self.flat, self.pg = module, flat, process_group
         self.world = dist.get_world_size(process_group)
+        # RCCL averages inside the collective; gloo (CPU tests) has no AVG and gets an explicit scale in finalize()
+        self._op = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else dist.ReduceOp.SUM
         if broadcast:
             dist.broadcast(flat.flat_p, src=0, group=process_group)
             for b in module.buffers():
@@ -79,16 +81,22 @@ class FlatDDP:
     def _launch(self, bi: int) -> None:
         lo, hi = self.ranges[bi]
         g = self.flat.flat_g
-        if g.is_cuda:
-            # a bucket mixes gradients produced on the main stream (autograd accumulation) and on the operators' side
-            # stream (weight-gradient GEMMs): the launching stream waits for the other one; the collective's own stream
-            # then orders itself after the launching stream
-            from . import ops
-            cur = torch.cuda.current_stream(g.device)
-            for other in (self._main_stream, ops.side_stream(g.device)):
-                if other is not None and other != cur:
-                    cur.wait_stream(other)
-        self._handles[bi] = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if not g.is_cuda:
+            self._handles[bi] = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            return
+        # a bucket mixes gradients produced on the main stream (autograd accumulation) and on the operators' side stream
+        # (weight-gradient GEMMs).  The collective is enqueued from a third, kernel-less stream that waits for both, so
+        # neither of the two compute streams stalls on the other; RCCL's own stream orders itself after that stream.
+        from . import ops
+        main = self._main_stream or torch.cuda.current_stream(g.device)
+        launch = ops.launch_stream(g.device, main)
+        launch.wait_stream(main)
+        launch.wait_stream(ops.side_stream(g.device))
+        cur = torch.cuda.current_stream(g.device)
+        if cur != main:
+            launch.wait_stream(cur)
+        with torch.cuda.stream(launch):
+            self._handles[bi] = dist.all_reduce(g[lo:hi], op=self._op, group=self.pg, async_op=True)
 
     def reset(self) -> None:
         """Call before each backward (after zero_grad), on the stream that will run the backward pass."""
@@ -104,8 +112,8 @@ class FlatDDP:
             if self._handles[bi] is None:
                 self._launch(bi)
         for h in self._handles:
-            h.wait()
-        if self.world > 1:
+            h.wait()                   # the current stream waits for the collective's stream (no host block on GPUs)
+        if self.world > 1 and self._op == dist.ReduceOp.SUM:
             self.flat.flat_g.mul_(1.0 / self.world)
 
     def remove_hooks(self) -> None:

@@ -278,14 +278,60 @@ DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small par
 GRAD_SIDE_HOOKS: list = []
 _WGRAD_OVERLAPPED = False      # True while a weight-gradient GEMM is being enqueued on the side stream
 _SIDE_STREAMS = {}
+_LAUNCH_STREAMS = {}
+_SIDE_STREAM_PROBES = {}       # device -> number of candidate streams tried (diagnostics)
 _JOIN_PENDING = set()
 
 
+def _streams_overlap(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", spin_us: int = 300) -> bool:
+    """True when a kernel on ``cand`` executes while one on ``main`` is still running.  The HIP runtime multiplexes
+    streams onto a few hardware queues; two streams that share one are serialised, and which ones collide depends on
+    every stream created before (an RCCL communicator shifts the assignment: measured 37.7 -> 42.0 ms per step with
+    the weight gradients silently serialised behind the main stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    main.synchronize()
+    cand.synchronize()
+    e0.record(main)
+    L.check(L.lib.uclstm_stream_spin(spin_us, C.c_void_p(main.cuda_stream)), "stream_spin")
+    L.check(L.lib.uclstm_stream_spin(spin_us, C.c_void_p(cand.cuda_stream)), "stream_spin")
+    e1.record(cand)
+    cand.synchronize()
+    main.synchronize()
+    return e0.elapsed_time(e1) < 1.5e-3 * spin_us
+
+
+def _pick_stream(device, others) -> tuple:
+    """(stream, tried): the first of up to eight fresh streams that demonstrably runs concurrently with every stream in
+    ``others``; the first candidate (and a warning) when none does."""
+    cands = []
+    if os.environ.get("UCLSTM_SIDE_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        for _ in range(8):
+            cands.append(torch.cuda.Stream(device=device))
+            if all(_streams_overlap(o, cands[-1]) for o in others):
+                return cands[-1], len(cands)
+        import warnings
+        warnings.warn("unet_convlstm_amd: no HIP stream runs concurrently with the ones in use; work meant to overlap the "
+                      "backward pass will be serialised behind it (try GPU_MAX_HW_QUEUES=8)")
+    return (cands[0] if cands else torch.cuda.Stream(device=device)), len(cands)
+
+
 def side_stream(device) -> "torch.cuda.Stream":
+    """The second stream of ``device`` (weight gradients).  Chosen once, at first use, as a stream that runs concurrently
+    with the stream current at that moment."""
     key = str(device)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key], _SIDE_STREAM_PROBES[key] = _pick_stream(device, [torch.cuda.current_stream(device)])
     return _SIDE_STREAMS[key]
+
+
+def launch_stream(device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+    """A third stream that carries no kernels, only waits: data-parallel code enqueues its collectives from it so that
+    neither ``main`` nor the side stream ever blocks on the other.  It must not share a hardware queue with either (a
+    wait packet would hold back the kernels queued behind it)."""
+    key = str(device)
+    if key not in _LAUNCH_STREAMS:
+        _LAUNCH_STREAMS[key], _ = _pick_stream(device, [main, side_stream(device)])
+    return _LAUNCH_STREAMS[key]
 
 
 def _schedule_join(device) -> None:
