@@ -15,7 +15,8 @@ import re
 import torch  # noqa: F401  (load order matters, see above)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libuclstm.so")
+# UCLSTM_LIB: another build of the same library (same-box A/B timing of kernel variants); it must exist and match the ABI
+LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
 ABI_VERSION = 5
