@@ -305,6 +305,8 @@ def _pick_stream(device, others) -> tuple:
     ``others``; the first candidate (and a warning) when none does."""
     cands = []
     if os.environ.get("UCLSTM_SIDE_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        # first launch of the spin kernel outside the timed comparison (code-object load)
+        L.check(L.lib.uclstm_stream_spin(1, C.c_void_p(others[0].cuda_stream)), "stream_spin")
         for _ in range(8):
             cands.append(torch.cuda.Stream(device=device))
             if all(_streams_overlap(o, cands[-1]) for o in others):
