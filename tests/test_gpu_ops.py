@@ -162,6 +162,78 @@ def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path, W):
     torch.testing.assert_close(res["ring"]["stats"], res["generic"]["stats"], rtol=1e-4, atol=1e-2)
 
 
+def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
+    """The patch shape of the forward kernel (activations of a 64-channel chunk staged once, nine taps as shifted LDS
+    reads, 128 x 256 tiles) walks K in the same order as the per-tap loop, so every output must be bit-identical and the
+    BatchNorm partial sums equal up to their f32 summation order.  Covers: one image per tile (16x16), four images per tile
+    (8x8), image rows (32x32, 64x64), tiles that start mid-row and cross an image boundary (16x24), a second source, a
+    partial last panel tile (N = 192), split-K slabs, the fused ConvLSTM epilogue.  The per-tap loop runs in a subprocess
+    with UCLSTM_FWD_PATCH=0 (the switch is read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        import unet_convlstm_amd as U
+        from unet_convlstm_amd import ops
+        torch.manual_seed(33)
+        res = {}
+        #        imgs H   W   C0   C1   Co  groups
+        cases = [(8, 16, 16, 64, 0, 128, 2), (16, 8, 8, 128, 64, 256, 4), (4, 32, 32, 64, 0, 192, 1), (2, 64, 64, 128, 0, 128, 1),
+                 (8, 16, 24, 64, 64, 128, 1)]
+        for ci, (N, H, W, C0, C1, Co, groups) in enumerate(cases):
+            xs = [(torch.randn(N, H, W, C0) * 0.7).to(torch.bfloat16).cuda()]
+            if C1:
+                xs.append((torch.randn(N, H, W, C1) * 0.7).to(torch.bfloat16).cuda())
+            cs = [C0] + ([C1] if C1 else [])
+            w = (torch.randn(Co, C0 + C1, 3, 3) * 0.05).cuda()
+            b = (torch.randn(Co) * 0.3).cuda()
+            pd = ops.conv_pack_desc(Co, C0 + C1, cs, cs)
+            wp, bp = ops.pack_weights(pd, w), ops.pack_bias(pd, b)
+            out = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device="cuda")
+            tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups, Co)
+            stats = torch.full((groups, tpg, Co, 2), float("nan"), device="cuda")
+            ops.igemm_store([ops.SrcView(t) for t in xs], wp, (H, W), N, [(out, 0, Co, 0, 1, 0, 0)], ktap=3, pad=1, groups=groups, bias=bp,
+                            stats=stats)
+            res["store%%d" %% ci] = out.cpu()
+            res["stats%%d" %% ci] = stats.sum(1).cpu()
+            # the same convolution as split-K slabs (K ranges of whole chunks: ksteps = 9 * chunks)
+            ksteps = wp.shape[1] // 64
+            ks = 2 if (ksteps // 9) %% 2 == 0 else 1
+            nsl = ops.ksplit_used(wp.shape[1], ks)
+            acc = torch.full((nsl, N * H * W, wp.shape[0]), float("nan"), device="cuda")
+            ops.igemm_atomic([ops.SrcView(t) for t in xs], wp, (H, W), N, acc, ks, ktap=3, pad=1, slabs=True)
+            res["slab%%d" %% ci] = acc.cpu()
+        # fused ConvLSTM cell: 16 images of 4x... 16x16 with Cx = Hd = 64 (N = 256 gate rows)
+        B, H, W, Cx, Hd = 4, 16, 16, 64, 64
+        x = (torch.randn(B, H, W, Cx) * 0.5).to(torch.bfloat16).cuda()
+        h = (torch.randn(B, H, W, Hd) * 0.5).to(torch.bfloat16).cuda()
+        c = torch.randn(B, H, W, Hd).cuda()
+        w = (torch.randn(4 * Hd, Cx + Hd, 3, 3) * 0.05).cuda()
+        bias = (torch.randn(4 * Hd) * 0.2).cuda()
+        pd = ops.lstm_pack_desc(Hd, Cx)
+        wp, bp = ops.pack_weights(pd, w), ops.pack_bias(pd, bias)
+        c_out, h_out = torch.empty_like(c), torch.empty_like(h)
+        gates = torch.empty(B, H, W, 4 * Hd, dtype=torch.bfloat16, device="cuda")
+        ops.igemm_lstm(x, h, wp, bp, c, c_out, h_out, gates)
+        res["lstm_c"], res["lstm_h"], res["lstm_g"] = c_out.cpu(), h_out.cpu(), gates.cpu()
+        torch.save(res, sys.argv[1])
+    """ % ROOT_DIR)
+    res = {}
+    for tag, val in (("patch", "1"), ("pertap", "0")):
+        f = str(tmp_path / (tag + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, UCLSTM_FWD_PATCH=val), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2500:]
+        res[tag] = torch.load(f)
+    for k, v in res["patch"].items():
+        ref = res["pertap"][k]
+        assert bool(torch.isfinite(v.float()).all()), k
+        if k.startswith("stats"):
+            torch.testing.assert_close(v, ref, rtol=1e-4, atol=1e-2, msg=k)
+        else:
+            assert torch.equal(v, ref), f"{k}: max abs diff {float((v.float() - ref.float()).abs().max())}"
+    assert float(res["patch"]["store0"].float().abs().max()) > 0.1
+
+
 def test_conv3x3_padded_second_source_and_groups_stats():
     """cat([skip, up]) with the upsampled map smaller than the skip (F.pad offsets) + per-group BN partial sums."""
     torch.manual_seed(2)

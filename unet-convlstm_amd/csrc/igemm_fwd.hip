@@ -40,19 +40,22 @@ struct Derived {
     int ksplit;      // K ranges (UCLSTM_EPI_ATOMIC only, else 1)
     int kper;        // K steps per range
     FastDiv dHW, dW; // pixel index -> (image, y, x)
+    FastDiv dPHW, dW2;   // padded-flat index -> (image, padded y, padded x)   (patch shape only)
     uint32_t xbias[2];   // bytes the source descriptor starts before the tensor (tap (0,0) of a border pixel is "negative")
     uint32_t xbytes[2];  // descriptor size: tensor bytes + bias
     uint32_t wbytes;     // panel bytes
 };
 
-// Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64).
-// (A 128 x 256 / 512-thread shape with a 3-stage ring and counted vmcnt measured 5-12 % slower on every layer and was
-// removed: profiles/round1_notes.md.)
+// Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64);
+// 2 = 128 rows x 256 pixels, waves 2x4, ONE block per CU, the "patch" K loop (below).
+// (A 128 x 256 / 512-thread shape with a 3-stage ring and counted vmcnt over the per-tap staging measured 5-12 % slower on
+// every layer and was removed: profiles/round1_notes.md.)
 template <int SHP>
 struct Shape {
     static constexpr int WN = SHP == 1 ? 1 : 2;  // waves along panel rows
     static constexpr int WM = SHP == 0 ? 2 : 4;  // waves along pixels
     static constexpr int NT = 64 * WN * WM;      // threads per block
+    static constexpr int MINB = SHP == 2 ? 1 : 2;    // blocks per CU the register budget is sized for
     static constexpr int RS = NT / 8;            // rows covered by one DMA round of the whole block
     static constexpr int TBN = 64 * WN;          // panel rows per tile
     static constexpr int TBM = 64 * WM;          // pixels per tile
@@ -62,12 +65,17 @@ struct Shape {
     static constexpr int WBYTES = TBN * BK * 2;
     static constexpr int STAGE = XBYTES + WBYTES;
     static constexpr int STAGES = 2;
-    static constexpr int SMEM = STAGES * STAGE;  // 64 KiB / 80 KiB
+    // patch shape: two activation patches of PROWS padded pixels (128 B each) + a ring of three weight tiles
+    static constexpr int PROWS = 400;
+    static constexpr int PBYTES = PROWS * BK * 2;             // 51200
+    static constexpr int PROUNDS = (PROWS + RS - 1) / RS;     // 7 DMA rounds of 64 rows (the last one partial)
+    static constexpr int WSLOTS = 3;
+    static constexpr int SMEM = SHP == 2 ? 2 * PBYTES + WSLOTS * WBYTES : STAGES * STAGE;  // 64 KiB / 80 KiB / 148 KiB
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
 template <int EPI, int SHP, int NSRC>
-__global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+__global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
     using SH = Shape<SHP>;
     constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR, NT = SH::NT, RS = SH::RS;
@@ -96,6 +104,161 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     const int rows_valid = min(TBM, dv.Mg - m_local0);
     const int n0 = nt * TBN;
     const int HW = d.H * d.W;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    if constexpr (SHP == 2) {
+        // ---- patch K loop (3x3 / pad 1 / stride 1, every source the size of the output, C % 64 == 0) ----------------
+        // The per-tap loop below stages the SAME activation rows nine times per 64-channel chunk (once per tap, shifted).
+        // Skipping eight of the nine stagings (wrong results, timing only) ran the 3x3 layers 12-30 % faster: the LDS-DMA
+        // issue (60-180 cycles of the issuing wave each, guide) is what the per-tap loop is bound by, not the MFMAs.  Here a
+        // chunk's activations are staged ONCE, as a patch: the tile's 256 consecutive pixels and their halo, laid out by
+        // PADDED-FLAT index gp = img*(H+2)(W+2) + yp*(W+2) + xp (the zero border is part of the index space; border rows
+        // are zero-filled by out-of-range DMA).  Tap (dy,dx) of pixel p is patch row prow(p) + dy*(W+2) + dx: nine shifted
+        // LDS reads of one staging.  Per chunk a wave issues <= 7 patch pieces + 9 x 2 weight pieces instead of 9 x 8.
+        //   LDS: 2 patches x 400 rows x 128 B (the next chunk's patch lands while this one is multiplied) + a ring of three
+        //   128 x 128-B weight tiles (two K-steps in flight, counted vmcnt, one raw s_barrier per K-step).
+        constexpr int PROUNDS = SH::PROUNDS, PBYTES = SH::PBYTES, WSLOT = SH::WBYTES;
+        unsigned char* const Wring = smem + 2 * PBYTES;
+        const int W2 = d.W + 2;
+        const int PHW = (d.H + 2) * W2;
+        const int lrow0 = tid >> 3;                        // row within a 64-row DMA round
+        const int lchunk = (tid & 7) ^ (lrow0 & 7);        // linear destination, swizzled source (as the per-tap loop)
+        const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].ptr, 0, dv.xbytes[0], 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx1 =
+            NSRC > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)d.src[1].ptr, 0, dv.xbytes[1], 0x00020000) : rsx0;
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, dv.wbytes, 0x00020000);
+
+        // padded-flat index of tap (0,0) of the tile's first pixel
+        int gp0;
+        {
+            const uint32_t m = (uint32_t)m0;
+            const int img = (int)fdiv(m, dv.dHW);
+            const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+            const int y = (int)fdiv(rem, dv.dW);
+            gp0 = img * PHW + y * W2 + ((int)rem - y * d.W);
+        }
+        // patch rows this lane stages (row lrow0 + 64*i): source PIXEL index, or "outside" (zero border / beyond the batch)
+        uint32_t ppix[PROUNDS];
+        uint32_t pout = 0;
+#pragma unroll
+        for (int i = 0; i < PROUNDS; ++i) {
+            const uint32_t gp = (uint32_t)(gp0 + lrow0 + SH::RS * i);
+            const int img = (int)fdiv(gp, dv.dPHW);
+            const uint32_t rem = gp - (uint32_t)img * (uint32_t)PHW;
+            const int yp = (int)fdiv(rem, dv.dW2);
+            const int xp = (int)rem - yp * W2;
+            const bool in = yp >= 1 && yp <= d.H && xp >= 1 && xp <= d.W && img < d.n_img;
+            ppix[i] = (uint32_t)((img * d.H + (yp - 1)) * d.W + (xp - 1));
+            pout |= in ? 0u : (1u << i);
+        }
+        // patch rows this lane READS: pixel wpx*64 + b*16 + l15, tap (0,0)
+        int prow[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t m = (uint32_t)(m0 + min(wpx * 64 + b * 16 + l15, rows_valid - 1));
+            const int img = (int)fdiv(m, dv.dHW);
+            const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+            const int y = (int)fdiv(rem, dv.dW);
+            prow[b] = img * PHW + y * W2 + ((int)rem - y * d.W) - gp0;
+        }
+        uint32_t wvoff[SH::WR];
+#pragma unroll
+        for (int i = 0; i < SH::WR; ++i) {
+            const int nrow = n0 + lrow0 + SH::RS * i;
+            wvoff[i] = nrow < d.N ? (uint32_t)(2 * (nrow * d.Ktot + lchunk * 8)) : OOB;
+        }
+        const int spt = (dv.kseg0 + dv.kseg1) / BK;
+        const int s0steps = dv.kseg0 / BK;
+        const int wrow_lds = wave * 8 * 128;
+        const int nsteps = kstep_end - kstep_begin;              // a multiple of 9, starting on a chunk boundary (host)
+        const int chunk_begin = kstep_begin / 9;
+        const int nchunks = nsteps / 9;
+
+        // one DMA round (64 rows) of the patch of chunk `chunk` into patch buffer `pb`
+#define PATCH_ROUND(i_, chunk_, pb_)                                                                                      \
+        do {                                                                                                              \
+            if ((i_) * SH::RS + wave * 8 < SH::PROWS) {                                                                    \
+                const bool s1_ = NSRC > 1 && (chunk_) >= s0steps;                                                          \
+                const int c0_ = ((chunk_) - (s1_ ? s0steps : 0)) * BK;                                                     \
+                const int C_ = s1_ ? d.src[1].C : d.src[0].C;                                                              \
+                const uint32_t off_ = ((pout >> (i_)) & 1u) ? OOB : ppix[i_] * (uint32_t)(2 * C_) + (uint32_t)(lchunk * 16); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s1_ ? rsx1 : rsx0,                                                \
+                                                         (lds_ptr)(smem + (pb_) * PBYTES + (i_) * SH::RS * 128 + wrow_lds), 16, \
+                                                         off_, (uint32_t)(2 * c0_), 0, 0);                                  \
+            }                                                                                                             \
+        } while (0)
+        // the weight tile of K-step (chunk, tap) into ring slot `slot`
+#define WTILE(chunk_, tap_, slot_)                                                                                        \
+        do {                                                                                                              \
+            const uint32_t koff_ = (uint32_t)((tap_) * spt + (chunk_)) * (BK * 2);                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < SH::WR; ++i_)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(Wring + (slot_) * WSLOT + i_ * SH::RS * 128 + wrow_lds), 16, \
+                                                         wvoff[i_], koff_, 0, 0);                                          \
+        } while (0)
+
+        // prologue: first patch, weight tiles of steps 0 and 1 (issue order matters for the counted waits below)
+#pragma unroll
+        for (int i = 0; i < PROUNDS; ++i) PATCH_ROUND(i, chunk_begin, 0);
+        WTILE(chunk_begin, 0, 0);
+        WTILE(chunk_begin, 1, 1);
+
+        int slot = 0;                         // ring slot of the current K-step
+        for (int ci = 0; ci < nchunks; ++ci) {
+            const int chunk = chunk_begin + ci;
+            const bool more = ci + 1 < nchunks;
+            const unsigned char* const P = smem + (ci & 1) * PBYTES;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // everything but the two youngest pieces (the weight tile of the NEXT step) has landed: this step's weight
+                // tile and, at tap 0, the whole patch
+                if (more || tap < 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // every wave is past its reads of the previous step: its ring slot and the other patch buffer are free
+                if (more && tap < PROUNDS) PATCH_ROUND(tap, chunk + 1, (ci + 1) & 1);
+                {
+                    const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+                    const int c2 = tap + 2 >= 9 ? chunk + 1 : chunk;
+                    int s2 = slot + 2;
+                    s2 = s2 >= 3 ? s2 - 3 : s2;
+                    if (more || tap + 2 < 9) WTILE(c2, t2, s2);
+                }
+                const int toff = (tap / 3) * W2 + (tap % 3);
+                const unsigned char* const Wt = Wring + slot * WSLOT;
+                bf16x8 wf[4], xf[4];
+                int xaddr[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = prow[b] + toff;
+                    xaddr[b] = r * 128 + ((lq ^ (r & 7)) << 4);
+                }
+                const int choffw = (lq ^ (l15 & 7)) << 4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + (choffw ^ (h << 6)));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(P + (xaddr[b] ^ (h << 6)));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                }
+                slot = slot + 1 >= 3 ? 0 : slot + 1;
+            }
+        }
+#undef PATCH_ROUND
+#undef WTILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
 
     // ---- operand staging: direct-to-LDS buffer loads (16 B per lane, guide section 5) ----
     // DMA instruction i of wave w fills LDS rows RS*i + 8*w + (lane>>3), 16-byte position lane&7 (1 KiB contiguous per
@@ -154,12 +317,6 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
         wvoff[i] = nrow < d.N ? (uint32_t)(2 * (nrow * d.Ktot + lchunk * 8)) : OOB;
     }
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // K-step cursor of the NEXT load.  The panel's K axis is (tap, source, channel); the loop walks it CHANNEL-CHUNK MAJOR,
     // TAP MINOR: the taps of one 64-channel chunk are consecutive steps, so the nine shifted reads of the same activation
     // cache lines come back-to-back and hit in L2.  (Tap-major order re-read every activation line once per tap from
@@ -176,7 +333,6 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
         c0 = (s ? chunk - s0steps : chunk) * BK;
     }
 
-    typedef __attribute__((address_space(3))) void* lds_ptr;
     const int wrow_lds = wave * 8 * 128;               // this wave's first row in every RS-row group (bytes)
 
     auto issue_src = [&](unsigned char* X) {
@@ -271,6 +427,8 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
     }
     step_body((nsteps - 1) & 1, std::false_type{});
     __syncthreads();
+
+    }   // per-tap loop (SHP 0 / 1)
 
     // ---- epilogue ----
     if constexpr (EPI == UCLSTM_EPI_LSTM) {
@@ -384,16 +542,22 @@ __global__ __launch_bounds__(Shape<SHP>::NT, 2) void igemm_fwd_kernel(const ucls
         }
         __syncthreads();
 
-        if (d.stats && tid < TBN) {
-            const int n = n0 + tid;
+        // the patch shape's 256-pixel tile fills the statistics rows of the two 128-pixel tiles it covers, so the buffer
+        // layout (uclstm_igemm_tiles_per_group) does not depend on which of the two kernels ran
+        constexpr int HALVES = SHP == 2 ? 2 : 1;
+        if (d.stats && tid < TBN * HALVES) {
+            const int half = tid / TBN;
+            const int col = tid - half * TBN;
+            const int n = n0 + col;
             if (n < d.N) {
                 float s1 = 0.f, s2 = 0.f;
-                for (int r = 0; r < rows_valid; ++r) {
-                    const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + tid * 2));
+                const int r1 = min(rows_valid, (half + 1) * (TBM / HALVES));
+                for (int r = half * (TBM / HALVES); r < r1; ++r) {
+                    const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + col * 2));
                     s1 += v;
                     s2 += v * v;
                 }
-                float* sp = d.stats + ((long)mt * d.N + n) * 2;
+                float* sp = d.stats + ((long)(mt * HALVES + half) * d.N + n) * 2;
                 sp[0] = s1;
                 sp[1] = s2;
             }
@@ -757,6 +921,33 @@ inline int pick_shape(int N, int64_t /*mg*/, int /*groups*/, int epi) {
 inline int shape_pixels(int shp) { return shp == 0 ? 128 : 256; }
 inline int shape_rows(int shp) { return shp == 1 ? 64 : 128; }
 
+// Rows a 256-pixel tile's patch can span in padded-flat index space (see the patch K loop): 255 steps between its first
+// and last pixel, +2 per image-row boundary crossed, +(2W+6) per image boundary crossed, plus the reach of tap (2,2).
+inline int patch_rows_max(int H, int W, int64_t mg) {
+    const int64_t HW = (int64_t)H * W;
+    int64_t R, I;
+    if (mg % 256 == 0 && 256 % W == 0 && (HW % 256 == 0 || 256 % HW == 0)) {      // tiles start on image-row boundaries
+        R = 256 / W - 1;
+        I = HW >= 256 ? 0 : 256 / HW - 1;
+    } else {
+        R = (254 + W) / W;
+        I = (254 + HW) / HW;
+    }
+    return (int)(255 + 2 * (R - I) + (2 * W + 6) * I + 2 * (W + 2) + 3);
+}
+
+// The launch conditions of the patch shape (SHP 2); everything else takes the per-tap loop.
+inline bool patch_ok(const uclstm_igemm_desc& d, int64_t mg) {
+    static const bool off = [] { const char* e = getenv("UCLSTM_FWD_PATCH"); return e && e[0] == '0'; }();
+    if (off || d.ktap != 3 || d.pad != 1 || d.scale != 1 || d.N <= 64 || (mg % 256)) return false;
+    for (int s = 0; s < d.nsrc; ++s) {
+        const uclstm_src& S = d.src[s];
+        if ((S.C % 64) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
+    }
+    if ((int64_t)d.n_img * (d.H + 2) * (d.W + 2) >= ((int64_t)1 << 30)) return false;
+    return patch_rows_max(d.H, d.W, mg) <= Shape<2>::PROWS;
+}
+
 template <int EPI, int SHP, int NSRC>
 int32_t launch_n(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
     static bool attr_done = false;
@@ -819,7 +1010,16 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
-    const int shp = pick_shape(d.N, mg, d.groups, d.epi);
+    int shp = pick_shape(d.N, mg, d.groups, d.epi);
+    bool patch = patch_ok(d, mg);
+    if (patch && d.epi == UCLSTM_EPI_ATOMIC) {            // K ranges must be whole 64-channel chunks (9 taps each)
+        if (d.ksplit < 1) return UCLSTM_E_BADARG;
+        const int kper = (d.Ktot / BK + d.ksplit - 1) / d.ksplit;
+        patch = (kper % 9) == 0;
+    }
+    if (patch) shp = 2;
+    dv.dPHW = make_fastdiv((uint32_t)((d.H + 2) * (d.W + 2)));
+    dv.dW2 = make_fastdiv((uint32_t)(d.W + 2));
     const int bm = shape_pixels(shp), bn = shape_rows(shp);
     dv.Mg = (int)mg;
     dv.tpg = (int)((mg + bm - 1) / bm);
@@ -869,8 +1069,11 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
                       (uint32_t)((int64_t)d.n_img * d.H * d.W * 64 * 2), dv.tpg);
         return UCLSTM_OK;
     }
-    if (d.epi == UCLSTM_EPI_LSTM) return launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
-    if (d.epi == UCLSTM_EPI_ATOMIC) return shp == 1 ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 0>(d, dv, nblk, st);
+    if (d.epi == UCLSTM_EPI_LSTM) return shp == 2 ? launch<UCLSTM_EPI_LSTM, 2>(d, dv, nblk, st) : launch<UCLSTM_EPI_LSTM, 0>(d, dv, nblk, st);
+    if (d.epi == UCLSTM_EPI_ATOMIC)
+        return shp == 2 ? launch<UCLSTM_EPI_ATOMIC, 2>(d, dv, nblk, st)
+                        : shp == 1 ? launch<UCLSTM_EPI_ATOMIC, 1>(d, dv, nblk, st) : launch<UCLSTM_EPI_ATOMIC, 0>(d, dv, nblk, st);
+    if (shp == 2) return launch<UCLSTM_EPI_STORE, 2>(d, dv, nblk, st);
     if (shp == 1) return launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st);
     return launch<UCLSTM_EPI_STORE, 0>(d, dv, nblk, st);
 }
