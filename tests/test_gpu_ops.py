@@ -166,7 +166,7 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
     """The patch shape of the forward kernel (activations of a 64-channel chunk staged once, nine taps as shifted LDS
     reads, 128 x 256 tiles) walks K in the same order as the per-tap loop, so every output must be bit-identical and the
     BatchNorm partial sums equal up to their f32 summation order.  Covers: one image per tile (16x16), four images per tile
-    (8x8), image rows (32x32, 64x64), tiles that start mid-row and cross an image boundary (16x24), a second source, a
+    (8x8), sixteen (4x4), image rows (32x32, 64x64), tiles that start mid-row and cross an image boundary (16x24), a second source, a
     partial last panel tile (N = 192), split-K slabs, the fused ConvLSTM epilogue.  The per-tap loop runs in a subprocess
     with UCLSTM_FWD_PATCH=0 (the switch is read once per process)."""
     import subprocess, sys, textwrap
@@ -179,7 +179,7 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         res = {}
         #        imgs H   W   C0   C1   Co  groups
         cases = [(8, 16, 16, 64, 0, 128, 2), (16, 8, 8, 128, 64, 256, 4), (4, 32, 32, 64, 0, 192, 1), (2, 64, 64, 128, 0, 128, 1),
-                 (8, 16, 24, 64, 64, 128, 1)]
+                 (8, 16, 24, 64, 64, 128, 1), (64, 4, 4, 128, 64, 256, 2)]
         for ci, (N, H, W, C0, C1, Co, groups) in enumerate(cases):
             xs = [(torch.randn(N, H, W, C0) * 0.7).to(torch.bfloat16).cuda()]
             if C1:

@@ -40,7 +40,7 @@ struct Derived {
     int ksplit;      // K ranges (UCLSTM_EPI_ATOMIC only, else 1)
     int kper;        // K steps per range
     FastDiv dHW, dW; // pixel index -> (image, y, x)
-    FastDiv dPHW, dW2;   // padded-flat index -> (image, padded y, padded x)   (patch shape only)
+    FastDiv dPHW, dW2;   // shared-zero padded index -> (image, y, x): divisors (H+1)(W+1) and W+1   (patch shape only)
     uint32_t xbias[2];   // bytes the source descriptor starts before the tensor (tap (0,0) of a border pixel is "negative")
     uint32_t xbytes[2];  // descriptor size: tensor bytes + bias
     uint32_t wbytes;     // panel bytes
@@ -66,11 +66,11 @@ struct Shape {
     static constexpr int STAGE = XBYTES + WBYTES;
     static constexpr int STAGES = 2;
     // patch shape: two activation patches of PROWS padded pixels (128 B each) + a ring of three weight tiles
-    static constexpr int PROWS = 400;
-    static constexpr int PBYTES = PROWS * BK * 2;             // 51200
-    static constexpr int PROUNDS = (PROWS + RS - 1) / RS;     // 7 DMA rounds of 64 rows (the last one partial)
+    static constexpr int PROWS = 448;
+    static constexpr int PBYTES = PROWS * BK * 2;             // 57344: 2 patches + 3 weight tiles = 160 KiB exactly
+    static constexpr int PROUNDS = (PROWS + RS - 1) / RS;     // 7 DMA rounds of 64 rows
     static constexpr int WSLOTS = 3;
-    static constexpr int SMEM = SHP == 2 ? 2 * PBYTES + WSLOTS * WBYTES : STAGES * STAGE;  // 64 KiB / 80 KiB / 148 KiB
+    static constexpr int SMEM = SHP == 2 ? 2 * PBYTES + WSLOTS * WBYTES : STAGES * STAGE;  // 64 KiB / 80 KiB / 160 KiB
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
@@ -117,16 +117,18 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         // The per-tap loop below stages the SAME activation rows nine times per 64-channel chunk (once per tap, shifted).
         // Skipping eight of the nine stagings (wrong results, timing only) ran the 3x3 layers 12-30 % faster: the LDS-DMA
         // issue (60-180 cycles of the issuing wave each, guide) is what the per-tap loop is bound by, not the MFMAs.  Here a
-        // chunk's activations are staged ONCE, as a patch: the tile's 256 consecutive pixels and their halo, laid out by
-        // PADDED-FLAT index gp = img*(H+2)(W+2) + yp*(W+2) + xp (the zero border is part of the index space; border rows
-        // are zero-filled by out-of-range DMA).  Tap (dy,dx) of pixel p is patch row prow(p) + dy*(W+2) + dx: nine shifted
-        // LDS reads of one staging.  Per chunk a wave issues <= 7 patch pieces + 9 x 2 weight pieces instead of 9 x 8.
-        //   LDS: 2 patches x 400 rows x 128 B (the next chunk's patch lands while this one is multiplied) + a ring of three
+        // chunk's activations are staged ONCE, as a patch: the tile's 256 consecutive pixels and their halo, laid out by a
+        // PADDED-FLAT index that shares its zeros: q(img,y,x) = img*(H+1)(W+1) + y*(W+1) + x, where column W of every row and
+        // row H of every image are zero (out-of-range DMA).  Column W is at once the right border of its row and the left
+        // border of the next one, row H the bottom border of its image and the top border of the next.  Tap (dy,dx) of pixel
+        // p is patch row prow(p) + (dy-1)*(W+1) + (dx-1): nine shifted LDS reads of one staging.  256 pixels span 307-406
+        // rows for 64x64 ... 4x4 images.  Per chunk a wave issues 7 patch pieces + 9 x 2 weight pieces instead of 9 x 8.
+        //   LDS: 2 patches x 448 rows x 128 B (the next chunk's patch lands while this one is multiplied) + a ring of three
         //   128 x 128-B weight tiles (two K-steps in flight, counted vmcnt, one raw s_barrier per K-step).
         constexpr int PROUNDS = SH::PROUNDS, PBYTES = SH::PBYTES, WSLOT = SH::WBYTES;
         unsigned char* const Wring = smem + 2 * PBYTES;
-        const int W2 = d.W + 2;
-        const int PHW = (d.H + 2) * W2;
+        const int W1 = d.W + 1;
+        const int PHW = (d.H + 1) * W1;
         const int lrow0 = tid >> 3;                        // row within a 64-row DMA round
         const int lchunk = (tid & 7) ^ (lrow0 & 7);        // linear destination, swizzled source (as the per-tap loop)
         const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].ptr, 0, dv.xbytes[0], 0x00020000);
@@ -134,30 +136,31 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             NSRC > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)d.src[1].ptr, 0, dv.xbytes[1], 0x00020000) : rsx0;
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, dv.wbytes, 0x00020000);
 
-        // padded-flat index of tap (0,0) of the tile's first pixel
-        int gp0;
+        // patch row 0 = tap (0,0) of the tile's first pixel = q(first) - (W+1) - 1 (negative only for the first tile)
+        int q0;
         {
             const uint32_t m = (uint32_t)m0;
             const int img = (int)fdiv(m, dv.dHW);
             const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
             const int y = (int)fdiv(rem, dv.dW);
-            gp0 = img * PHW + y * W2 + ((int)rem - y * d.W);
+            q0 = img * PHW + y * W1 + ((int)rem - y * d.W) - W1 - 1;
         }
-        // patch rows this lane stages (row lrow0 + 64*i): source PIXEL index, or "outside" (zero border / beyond the batch)
+        // patch rows this lane stages (row lrow0 + 64*i): source PIXEL index, or "outside" (shared zeros / beyond the batch)
         uint32_t ppix[PROUNDS];
         uint32_t pout = 0;
 #pragma unroll
         for (int i = 0; i < PROUNDS; ++i) {
-            const uint32_t gp = (uint32_t)(gp0 + lrow0 + SH::RS * i);
-            const int img = (int)fdiv(gp, dv.dPHW);
-            const uint32_t rem = gp - (uint32_t)img * (uint32_t)PHW;
-            const int yp = (int)fdiv(rem, dv.dW2);
-            const int xp = (int)rem - yp * W2;
-            const bool in = yp >= 1 && yp <= d.H && xp >= 1 && xp <= d.W && img < d.n_img;
-            ppix[i] = (uint32_t)((img * d.H + (yp - 1)) * d.W + (xp - 1));
+            const int q = q0 + lrow0 + SH::RS * i;
+            const uint32_t qu = (uint32_t)max(q, 0);
+            const int img = (int)fdiv(qu, dv.dPHW);
+            const uint32_t rem = qu - (uint32_t)img * (uint32_t)PHW;
+            const int yy = (int)fdiv(rem, dv.dW2);
+            const int xx = (int)rem - yy * W1;
+            const bool in = q >= 0 && yy < d.H && xx < d.W && img < d.n_img;
+            ppix[i] = (uint32_t)((img * d.H + yy) * d.W + xx);
             pout |= in ? 0u : (1u << i);
         }
-        // patch rows this lane READS: pixel wpx*64 + b*16 + l15, tap (0,0)
+        // patch rows this lane READS: the CENTRE tap of pixel wpx*64 + b*16 + l15
         int prow[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             const int img = (int)fdiv(m, dv.dHW);
             const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
             const int y = (int)fdiv(rem, dv.dW);
-            prow[b] = img * PHW + y * W2 + ((int)rem - y * d.W) - gp0;
+            prow[b] = img * PHW + y * W1 + ((int)rem - y * d.W) - q0;
         }
         uint32_t wvoff[SH::WR];
 #pragma unroll
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                     s2 = s2 >= 3 ? s2 - 3 : s2;
                     if (more || tap + 2 < 9) WTILE(c2, t2, s2);
                 }
-                const int toff = (tap / 3) * W2 + (tap % 3);
+                const int toff = (tap / 3 - 1) * W1 + (tap % 3 - 1);
                 const unsigned char* const Wt = Wring + slot * WSLOT;
                 bf16x8 wf[4], xf[4];
                 int xaddr[4];
@@ -921,8 +924,9 @@ inline int pick_shape(int N, int64_t /*mg*/, int /*groups*/, int epi) {
 inline int shape_pixels(int shp) { return shp == 0 ? 128 : 256; }
 inline int shape_rows(int shp) { return shp == 1 ? 64 : 128; }
 
-// Rows a 256-pixel tile's patch can span in padded-flat index space (see the patch K loop): 255 steps between its first
-// and last pixel, +2 per image-row boundary crossed, +(2W+6) per image boundary crossed, plus the reach of tap (2,2).
+// Rows a 256-pixel tile's patch can span in the shared-zero padded index space (see the patch K loop): 255 steps between
+// its first and last pixel, +1 per image-row boundary crossed, +(W+2) per image boundary crossed, plus the reach of the
+// corner taps on either side.
 inline int patch_rows_max(int H, int W, int64_t mg) {
     const int64_t HW = (int64_t)H * W;
     int64_t R, I;
@@ -933,18 +937,19 @@ inline int patch_rows_max(int H, int W, int64_t mg) {
         R = (254 + W) / W;
         I = (254 + HW) / HW;
     }
-    return (int)(255 + 2 * (R - I) + (2 * W + 6) * I + 2 * (W + 2) + 3);
+    return (int)(255 + (R - I) + (W + 2) * I + 2 * (W + 2) + 1);
 }
 
 // The launch conditions of the patch shape (SHP 2); everything else takes the per-tap loop.
 inline bool patch_ok(const uclstm_igemm_desc& d, int64_t mg) {
     static const bool off = [] { const char* e = getenv("UCLSTM_FWD_PATCH"); return e && e[0] == '0'; }();
     if (off || d.ktap != 3 || d.pad != 1 || d.scale != 1 || d.N <= 64 || (mg % 256)) return false;
+    if (d.Ktot < 2 * 9 * BK) return false;       // one chunk: nothing to amortise the patch over (K = 576 measured 11 % slower)
     for (int s = 0; s < d.nsrc; ++s) {
         const uclstm_src& S = d.src[s];
         if ((S.C % 64) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
     }
-    if ((int64_t)d.n_img * (d.H + 2) * (d.W + 2) >= ((int64_t)1 << 30)) return false;
+    if ((int64_t)d.n_img * (d.H + 1) * (d.W + 1) >= ((int64_t)1 << 30)) return false;
     return patch_rows_max(d.H, d.W, mg) <= Shape<2>::PROWS;
 }
 
@@ -1018,8 +1023,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
         patch = (kper % 9) == 0;
     }
     if (patch) shp = 2;
-    dv.dPHW = make_fastdiv((uint32_t)((d.H + 2) * (d.W + 2)));
-    dv.dW2 = make_fastdiv((uint32_t)(d.W + 2));
+    dv.dPHW = make_fastdiv((uint32_t)((d.H + 1) * (d.W + 1)));
+    dv.dW2 = make_fastdiv((uint32_t)(d.W + 1));
     const int bm = shape_pixels(shp), bn = shape_rows(shp);
     dv.Mg = (int)mg;
     dv.tpg = (int)((mg + bm - 1) / bm);
