@@ -74,6 +74,16 @@ struct Shape {
     static constexpr int OT_PITCH = TBN * 2 + 16;
 };
 
+// Sum over the 16 lanes of a DPP row with four v_add_f32 + DPP (xor 1, xor 2, half-row mirror, row mirror); every lane of the
+// row ends up with the total.  (__shfl_xor would be four ds_bpermute round trips per value.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));     // row_mirror
+    return v;
+}
+
 template <int EPI, int SHP, int NSRC>
 __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
@@ -530,6 +540,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                 if (d.col_scale) { const float4 t = *(const float4*)(d.col_scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
                 if (d.col_shift) { const float4 t = *(const float4*)(d.col_shift + n); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
             }
+            float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int prow = wpx * 64 + b * 16 + l15;
@@ -539,8 +550,28 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                     float v = (acc[a][b][r] + bs[r]) * sc[r] + sh[r];
                     if (d.relu) v = fmaxf(v, 0.f);
                     o.e[r] = f32_to_bf16(v);
+                    if constexpr (SHP == 2) {      // statistics of the ROUNDED values (what BatchNorm will read), from registers
+                        const float q = prow < rows_valid ? bf16_to_f32(o.e[r]) : 0.f;
+                        ps1[r] += q;
+                        ps2[r] += q * q;
+                    }
                 }
                 *(uint2*)(Ot + prow * OT_PITCH + col * 2) = o.u;
+            }
+            if constexpr (SHP == 2) {
+                // with one block per CU nothing hides a serial 128-row LDS walk per channel: reduce over the wave's 64 pixels
+                // with DPP row sums, leave one value per (wave, channel) in LDS for the two-wave add below
+                if (d.stats) {
+                    float* Red = (float*)(smem + TBM * OT_PITCH);       // [WM][TBN][2]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t1 = row16_sum(ps1[r]), t2 = row16_sum(ps2[r]);
+                        if (l15 == 0) {
+                            Red[(wpx * TBN + col + r) * 2] = t1;
+                            Red[(wpx * TBN + col + r) * 2 + 1] = t2;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -554,11 +585,16 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             const int n = n0 + col;
             if (n < d.N) {
                 float s1 = 0.f, s2 = 0.f;
-                const int r1 = min(rows_valid, (half + 1) * (TBM / HALVES));
-                for (int r = half * (TBM / HALVES); r < r1; ++r) {
-                    const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + col * 2));
-                    s1 += v;
-                    s2 += v * v;
+                if constexpr (SHP == 2) {
+                    const float* Red = (const float*)(smem + TBM * OT_PITCH);
+                    s1 = Red[((2 * half) * TBN + col) * 2] + Red[((2 * half + 1) * TBN + col) * 2];
+                    s2 = Red[((2 * half) * TBN + col) * 2 + 1] + Red[((2 * half + 1) * TBN + col) * 2 + 1];
+                } else {
+                    for (int r = 0; r < rows_valid; ++r) {
+                        const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + col * 2));
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
                 float* sp = d.stats + ((long)(mt * HALVES + half) * d.N + n) * 2;
                 sp[0] = s1;
@@ -609,15 +645,6 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
 //     sector-aligned pieces; BatchNorm partial sums by 16-lane shuffles + a 2-KiB LDS exchange.
 // Virtual row numbering: image k, row y -> v = k*(H+1) + y; v = k*(H+1) + H is the zero row shared by images k and k+1;
 // ring slot of v = (v + 1) mod 10.
-// Sum over the 16 lanes of a DPP row with four v_add_f32 + DPP (xor 1, xor 2, half-row mirror, row mirror); every lane of the
-// row ends up with the total.  (__shfl_xor would be four ds_bpermute round trips per value.)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));     // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));     // row_mirror
-    return v;
-}
 
 constexpr int C64_WBYTES = 9 * 64 * 128;            // 73728
 constexpr int C64_ROW = 66 * 128;                   // 8448
