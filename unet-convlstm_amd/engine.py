@@ -177,10 +177,18 @@ def train_step(model, optimizer, x, y, mask=None, use_mask=True, ddp=None, clip_
     optimizer.zero_grad(set_to_none=True)
     if ddp is not None:
         ddp.reset()
-    output, _ = model(x)
-    y_pred = _stack(output)
-    loss = compute_loss(y_pred, y, mask, use_mask)
-    loss.backward()
+    on_gpu = x.is_cuda
+    if on_gpu:
+        from . import ops
+        ops.prepack_begin()          # weights are fixed until optimizer.step(): pack this step's panels ahead, off the main stream
+    try:
+        output, _ = model(x)
+        y_pred = _stack(output)
+        loss = compute_loss(y_pred, y, mask, use_mask)
+        loss.backward()
+    finally:
+        if on_gpu:
+            ops.prepack_end()
     if ddp is not None:
         ddp.finalize()
     if isinstance(optimizer, FusedAdamW):
