@@ -22,7 +22,7 @@ from .optim import FlatParams
 
 class FlatDDP:
     def __init__(self, module: torch.nn.Module, flat: FlatParams, bucket_mb: float = 64.0, process_group=None,
-                 broadcast: bool = True):
+                 broadcast: bool = True, first_bucket_mb: float = 1.0):
         if not dist.is_initialized():
             raise RuntimeError("FlatDDP: torch.distributed is not initialised")
         self.module, self.flat, self.pg = module, flat, process_group
@@ -33,21 +33,35 @@ class FlatDDP:
             dist.broadcast(flat.flat_p, src=0, group=process_group)
             for b in module.buffers():
                 dist.broadcast(b, src=0, group=process_group)
-        # buckets: contiguous [start, end) slices, last parameters first
+        # buckets: contiguous [start, end) slices, last parameters first.  The bucket that holds parameter 0 completes only
+        # with the very last gradient of the backward pass, so its all-reduce is the one nothing can hide: it is kept small
+        # (first_bucket_mb), like the first bucket of torch's DistributedDataParallel.
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        first_cap = min(cap, max(1, int(first_bucket_mb * (1 << 20) / 4)))
+        n_front, size = 0, 0
+        while n_front < len(flat.params) - 1 and size + flat.params[n_front].numel() <= first_cap:
+            size += flat.params[n_front].numel()
+            n_front += 1
+        n_front = max(n_front, 1) if len(flat.params) > 1 else len(flat.params)
         self.buckets: List[List[int]] = []          # parameter indices per bucket
         self.ranges: List[tuple] = []
+
+        def close(cur):
+            lo = flat.offsets[cur[-1]]
+            hi = flat.offsets[cur[0]] + flat.params[cur[0]].numel()
+            self.buckets.append(cur)
+            self.ranges.append((lo, hi))
+
         cur: List[int] = []
         size = 0
-        for i in range(len(flat.params) - 1, -1, -1):
+        for i in range(len(flat.params) - 1, n_front - 1, -1):
             cur.append(i)
             size += flat.params[i].numel()
-            if size >= cap or i == 0:
-                lo = flat.offsets[cur[-1]]
-                hi = flat.offsets[cur[0]] + flat.params[cur[0]].numel()
-                self.buckets.append(cur)
-                self.ranges.append((lo, hi))
+            if size >= cap or i == n_front:
+                close(cur)
                 cur, size = [], 0
+        if n_front > 0 and len(flat.params) > 0:
+            close(list(range(n_front - 1, -1, -1)))
         self.bucket_of = {}
         for bi, idxs in enumerate(self.buckets):
             for i in idxs:
