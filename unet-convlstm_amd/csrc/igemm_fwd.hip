@@ -9,8 +9,11 @@
 // v_mfma_f32_16x16x32_bf16 with the PANEL as the MFMA A operand: a lane then owns 4 consecutive
 // output channels of one pixel, which makes the LSTM gate quadruple (i,f,g,o of one hidden
 // channel = 4 M-subtiles of a wave) lane-local and lets the epilogue pack 8-byte channel runs.
-// Two block shapes: 128 panel rows x 128 pixels (waves 2x2) and, for C_out <= 64 layers,
+// Block shapes of the per-tap loop: 128 panel rows x 128 pixels (waves 2x2) and, for C_out <= 64 layers,
 // 64 panel rows x 256 pixels (waves 1x4) so that no MFMA work is spent on absent channels.
+// A third shape (128 x 256, 8 waves, one block per CU) runs the PATCH loop that most 3x3 launches
+// take: the activations of a 64-channel chunk are staged once and the nine taps are shifted LDS
+// reads of that staging (see the comment at `if constexpr (SHP == 2)`).
 // LDS rows are 128 B, XOR-swizzled by (row & 7) on the 16-byte chunk (conflict-free
 // ds_read_b128, guide T2).  Operands go global->LDS directly through BUFFER descriptors
 // (buffer_load_dwordx4 ... lds, 16 B/lane).  Measured on gfx950 (tools/probes/): a lane whose
