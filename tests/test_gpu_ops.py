@@ -203,6 +203,11 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
             acc = torch.full((nsl, N * H * W, wp.shape[0]), float("nan"), device="cuda")
             ops.igemm_atomic([ops.SrcView(t) for t in xs], wp, (H, W), N, acc, ks, ktap=3, pad=1, slabs=True)
             res["slab%%d" %% ci] = acc.cpu()
+            if ci < 2:      # f32-atomic form of the same split (one shared accumulator): order-dependent rounding only
+                acc1 = torch.zeros((N * H * W, wp.shape[0]), device="cuda")
+                ops.igemm_atomic([ops.SrcView(t) for t in xs], wp, (H, W), N, acc1, ks, ktap=3, pad=1, slabs=False)
+                res["atom%%d" %% ci] = acc1.cpu()
+                res["slabsum%%d" %% ci] = acc.sum(0).cpu()
         # fused ConvLSTM cell: 16 images of 4x... 16x16 with Cx = Hd = 64 (N = 256 gate rows)
         B, H, W, Cx, Hd = 4, 16, 16, 64, 64
         x = (torch.randn(B, H, W, Cx) * 0.5).to(torch.bfloat16).cuda()
@@ -227,7 +232,10 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
     for k, v in res["patch"].items():
         ref = res["pertap"][k]
         assert bool(torch.isfinite(v.float()).all()), k
-        if k.startswith("stats"):
+        if k.startswith("atom"):
+            torch.testing.assert_close(v, ref, rtol=1e-4, atol=1e-4, msg=k)
+            torch.testing.assert_close(v, res["patch"]["slabsum" + k[4:]], rtol=1e-4, atol=1e-4, msg=k + " vs slab sum")
+        elif k.startswith("stats"):
             torch.testing.assert_close(v, ref, rtol=1e-4, atol=1e-2, msg=k)
         else:
             assert torch.equal(v, ref), f"{k}: max abs diff {float((v.float() - ref.float()).abs().max())}"
