@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 5
+#define UCLSTM_ABI_VERSION 6
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -113,6 +113,12 @@ int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_
  *   gradient (:90,:94), and with UCLSTM_EPI_LSTM the whole ConvLSTMCell.forward (:21-36:
  *   cat + conv + chunk + sigmoid/tanh + cell update in one kernel). */
 int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* d, void* stream);
+/* Which kernel uclstm_igemm_fwd would run for this descriptor (same validation, nothing is launched): 0 = per-tap loop,
+ * 128 x 128 tile; 1 = per-tap loop, 64 rows x 256 pixels (C_out <= 64); 2 = patch loop, 128 rows x 256 pixels (3x3 / pad 1 /
+ * stride 1, every source on the output grid with C % 64 == 0, >= 2 channel chunks, 256 | pixels per group, patch <= 448
+ * rows); 3 = the 64 -> 64-channel ring kernel.  Negative: UCLSTM_E_*.  Tests use it to assert that a parity case really
+ * exercised the kernel it is meant for. */
+int32_t uclstm_igemm_fwd_shape(const uclstm_igemm_desc* desc);
 /* Number of non-empty K ranges uclstm_igemm_fwd will use for (Ktot, requested ksplit): the slab count of acc_slab mode. */
 int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit);
 

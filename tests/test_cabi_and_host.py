@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     raw = C.CDLL(L.LIB_PATH)
     for s in syms:
         assert hasattr(raw, s), s
-    assert L.lib.uclstm_abi_version() == L.ABI_VERSION == 5
+    assert L.lib.uclstm_abi_version() == L.ABI_VERSION == 6
     assert L.lib.uclstm_build_arch() == b"gfx950"
 
 

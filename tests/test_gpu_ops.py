@@ -147,8 +147,9 @@ def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path, W):
         out = torch.empty(N, H, W, 64, dtype=torch.bfloat16, device="cuda")
         tpg = U._lib.lib.uclstm_igemm_tiles_per_group(N, H, W, groups, 64)
         stats = torch.full((groups, tpg, 64, 2), float("nan"), device="cuda")
+        ops.SHAPE_LOG = []
         ops.igemm_store([ops.SrcView(xn)], wp, (H, W), N, [(out, 0, 64, 0, 1, 0, 0)], ktap=3, pad=1, groups=groups, bias=bp, stats=stats)
-        torch.save({"out": out.cpu(), "stats": stats.sum(1).cpu()}, sys.argv[1])
+        torch.save({"out": out.cpu(), "stats": stats.sum(1).cpu(), "shape": ops.SHAPE_LOG[0]}, sys.argv[1])
     """ % ROOT_DIR)
     res = {}
     for tag, val in (("ring", "1"), ("generic", "0")):
@@ -157,6 +158,7 @@ def test_c64_ring_kernel_is_bit_identical_to_the_generic_kernel(tmp_path, W):
                            timeout=240)
         assert r.returncode == 0, r.stderr[-1500:]
         res[tag] = torch.load(f)
+    assert res["ring"]["shape"] == 3 and res["generic"]["shape"] == 1       # what the library says it launched
     assert torch.equal(res["ring"]["out"], res["generic"]["out"])
     assert bool(torch.isfinite(res["ring"]["stats"]).all())
     torch.testing.assert_close(res["ring"]["stats"], res["generic"]["stats"], rtol=1e-4, atol=1e-2)
@@ -177,8 +179,9 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         from unet_convlstm_amd import ops
         torch.manual_seed(33)
         res = {}
+        ops.SHAPE_LOG = []
         #        imgs H   W   C0   C1   Co  groups
-        cases = [(8, 16, 16, 64, 0, 128, 2), (16, 8, 8, 128, 64, 256, 4), (4, 32, 32, 64, 0, 192, 1), (2, 64, 64, 128, 0, 128, 1),
+        cases = [(8, 16, 16, 128, 0, 128, 2), (16, 8, 8, 128, 64, 256, 4), (4, 32, 32, 128, 0, 192, 1), (2, 64, 64, 128, 0, 128, 1),
                  (8, 16, 24, 64, 64, 128, 1), (64, 4, 4, 128, 64, 256, 2)]
         for ci, (N, H, W, C0, C1, Co, groups) in enumerate(cases):
             xs = [(torch.randn(N, H, W, C0) * 0.7).to(torch.bfloat16).cuda()]
@@ -221,6 +224,7 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         gates = torch.empty(B, H, W, 4 * Hd, dtype=torch.bfloat16, device="cuda")
         ops.igemm_lstm(x, h, wp, bp, c, c_out, h_out, gates)
         res["lstm_c"], res["lstm_h"], res["lstm_g"] = c_out.cpu(), h_out.cpu(), gates.cpu()
+        res["shapes"] = torch.tensor(ops.SHAPE_LOG)
         torch.save(res, sys.argv[1])
     """ % ROOT_DIR)
     res = {}
@@ -229,6 +233,9 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, UCLSTM_FWD_PATCH=val), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2500:]
         res[tag] = torch.load(f)
+    # the library reports which kernel each launch took: every launch of the first run the patch loop, none of the second
+    assert res["patch"]["shapes"].numel() >= 15 and bool((res["patch"].pop("shapes") == 2).all())
+    assert bool((res["pertap"].pop("shapes") == 0).all())
     for k, v in res["patch"].items():
         ref = res["pertap"][k]
         assert bool(torch.isfinite(v.float()).all()), k

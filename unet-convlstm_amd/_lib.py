@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -82,6 +82,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _PROTOS = {
     "uclstm_igemm_tiles_per_group": [_I, _I, _I, _I, _I],
     "uclstm_igemm_fwd": [C.POINTER(IgemmDesc), _P],
+    "uclstm_igemm_fwd_shape": [_P],
     "uclstm_igemm_ksplit_used": [_I, _I],
     "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
     "uclstm_igemm_wgrad_splits": [C.POINTER(WgradDesc)],

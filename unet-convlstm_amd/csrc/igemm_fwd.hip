@@ -1015,15 +1015,14 @@ extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit) {
     return (ksteps + kper - 1) / kper;
 }
 
-extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
-    if (!dp) return UCLSTM_E_BADARG;
-    const uclstm_igemm_desc& d = *dp;
+// Validation + launch plan shared by uclstm_igemm_fwd and uclstm_igemm_fwd_shape: derived constants, block shape, grid.
+static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64_t& nblk, int64_t& mg_out) {
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0 || d.groups <= 0 || d.n_img % d.groups) return UCLSTM_E_BADARG;
     if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
     if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
     for (int s = 0; s < d.nsrc; ++s)
         if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;
-    Derived dv{};
+    dv = Derived{};
     const int64_t lim = ((int64_t)1 << 31) - (1 << 22);      // descriptors are addressed with bit 31 = "out of range"
     for (int s = 0; s < d.nsrc; ++s) {
         const uclstm_src& S = d.src[s];
@@ -1045,7 +1044,8 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
-    int shp = pick_shape(d.N, mg, d.groups, d.epi);
+    shp = pick_shape(d.N, mg, d.groups, d.epi);
+    mg_out = mg;
     bool patch = patch_ok(d, mg);
     if (patch && d.epi == UCLSTM_EPI_ATOMIC) {            // K ranges must be whole 64-channel chunks (9 taps each)
         if (d.ksplit < 1) return UCLSTM_E_BADARG;
@@ -1068,7 +1068,7 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
         dv.kper = (dv.ksteps + d.ksplit - 1) / d.ksplit;
         dv.ksplit = (dv.ksteps + dv.kper - 1) / dv.kper;      // every K range is non-empty
     }
-    const int64_t nblk = (int64_t)dv.n_mtiles * dv.n_ntiles * dv.ksplit;
+    nblk = (int64_t)dv.n_mtiles * dv.n_ntiles * dv.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
 
     if (d.epi == UCLSTM_EPI_ATOMIC) {
@@ -1089,6 +1089,27 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
         return UCLSTM_E_BADARG;
     }
 
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_igemm_fwd_shape(const uclstm_igemm_desc* dp) {
+    if (!dp) return UCLSTM_E_BADARG;
+    Derived dv;
+    int shp = 0;
+    int64_t nblk = 0, mg = 0;
+    const int32_t rc = plan_fwd(*dp, dv, shp, nblk, mg);
+    if (rc != UCLSTM_OK) return rc;
+    return (c64_ok(*dp) && mg % 256 == 0) ? 3 : shp;
+}
+
+extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
+    if (!dp) return UCLSTM_E_BADARG;
+    const uclstm_igemm_desc& d = *dp;
+    Derived dv;
+    int shp = 0;
+    int64_t nblk = 0, mg = 0;
+    const int32_t rc = plan_fwd(d, dv, shp, nblk, mg);
+    if (rc != UCLSTM_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (c64_ok(d) && mg % 256 == 0) {        // its 256-pixel tiles are the generic 64x256 shape's tiles: same statistics rows
         static bool attr64 = false;

@@ -51,6 +51,16 @@ def _p(t: Optional[torch.Tensor]):
 PROFILE: Optional[list] = None
 
 
+# Optional record of which forward-family kernel each launch takes (uclstm_igemm_fwd_shape: 0 / 1 per-tap shapes, 2 patch loop,
+# 3 ring kernel): tests set it to a list to assert that a parity case exercised the kernel it is meant for.
+SHAPE_LOG: Optional[list] = None
+
+
+def _log_shape(d) -> None:
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append(int(L.lib.uclstm_igemm_fwd_shape(C.byref(d))))
+
+
 def _timed(kind: str, flops: float, launch, note: str = "") -> None:
     if PROFILE is None:
         launch()
@@ -468,6 +478,7 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
         _fill_seg(d.seg[i], *sg)
     d.stats = None if stats is None else stats.data_ptr()
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
+    _log_shape(d)
     _timed("igemm_fwd_store", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}")
 
@@ -507,6 +518,7 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
     if slabs and (acc_out.dim() != 3 or acc_out.shape[0] != ksplit_used(d.Ktot, ksplit) or not acc_out.is_contiguous()):
         raise L.UclstmError("igemm_atomic(slabs=True): acc_out must be a contiguous [ksplit_used, pixels, ld] tensor")
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
+    _log_shape(d)
     _timed("igemm_fwd_atomic", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
 
@@ -527,6 +539,7 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
     d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
     flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * (x.shape[3] + h_prev.shape[3])
+    _log_shape(d)
     _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
            f"M={B * H * W} N={d.N} K={d.Ktot}")
 
