@@ -217,8 +217,12 @@ int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, int32_t Cp,
 /* MaxPool2d(2) (train/unet.py:81)                                                      */
 /* ------------------------------------------------------------------------------------ */
 int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream);
-/* da must be zero-filled by the caller when H or W is odd. First maximum in window scan order wins (ATen rule). */
-int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream);
+/* da must be zero-filled by the caller when H or W is odd. First maximum in window scan order wins (ATen rule).
+ * add (may be NULL; H and W even): a second gradient of the same tensor, bf16 [n_img][H][W][Cp] -- da = add + scatter(dp).
+ * The UNet feeds every encoder output both to the next Down and to the decoder (train/unet.py:166-169, :188-196), so its
+ * gradient is always such a sum. */
+int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, const void* add, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* ConvLSTM backward point-wise part (autograd of train/unet.py:29-35)                  */

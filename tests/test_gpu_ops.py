@@ -694,3 +694,29 @@ def test_side_stream_is_probed_to_run_concurrently_with_the_main_stream():
     assert launch not in (main, side)
     assert ops._streams_overlap(main, launch) and ops._streams_overlap(side, launch)
     assert L.lib.uclstm_stream_spin(0, ops._stream()) != 0      # argument check
+
+
+@pytest.mark.parametrize("N,H,W,C", [(3, 8, 12, 16), (2, 9, 6, 8), (4, 32, 32, 64)])
+def test_maxpool_skip_backward_equals_pool_backward_plus_skip_gradient(N, H, W, C):
+    """ops.MaxPool2Skip hands the pooled tensor and an alias of its input (the UNet skip connection) to autograd and adds
+    the two gradients inside the max-pool backward kernel: bit-identical to MaxPool2 + autograd's own add (odd sizes take
+    the unfused path)."""
+    torch.manual_seed(9)
+    a = (torch.randn(N, H, W, C) * 0.7).to(torch.bfloat16).to(DEV)
+    gp = (torch.randn(N, H // 2, W // 2, C)).to(torch.bfloat16).to(DEV)
+    gs = (torch.randn(N, H, W, C)).to(torch.bfloat16).to(DEV)
+    a1 = a.clone().requires_grad_(True)
+    p1, s1 = ops.MaxPool2Skip.apply(a1)
+    torch.autograd.backward([p1, s1], [gp, gs])
+    a2 = a.clone().requires_grad_(True)
+    p2 = ops.MaxPool2.apply(a2)
+    torch.autograd.backward([p2, a2 * 1.0], [gp, gs])
+    assert torch.equal(p1, p2) and torch.equal(s1, a)
+    assert torch.equal(a1.grad, a2.grad)
+    # only one of the two consumers used
+    a3 = a.clone().requires_grad_(True)
+    p3, _ = ops.MaxPool2Skip.apply(a3)
+    p3.backward(gp)
+    a4 = a.clone().requires_grad_(True)
+    ops.MaxPool2.apply(a4).backward(gp)
+    assert torch.equal(a3.grad, a4.grad)

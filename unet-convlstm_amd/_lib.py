@@ -96,7 +96,7 @@ _PROTOS = {
     "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_param_grads": [_P, _I, _I, _I, _P, _P, _I, _P],
     "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
-    "uclstm_maxpool2_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "uclstm_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P, _L, _I, _P],
     "uclstm_lstm_fwd_pointwise": [_P, _I, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "uclstm_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],

@@ -353,8 +353,10 @@ __global__ void maxpool_fwd_kernel(const uint4* __restrict__ a, uint4* __restric
     }
 }
 
-__global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __restrict__ dp, uint4* __restrict__ da, int64_t chunks,
-                                   FastDiv dcpc, FastDiv dWo, FastDiv dHo, int H, int W) {
+// add (may be null): a second gradient of the pooled tensor's INPUT (the skip connection of the UNet: train/unet.py:166-169
+// feed x_k both to the next Down and to the decoder), summed here instead of by a separate elementwise kernel.
+__global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __restrict__ dp, const uint4* __restrict__ add,
+                                   uint4* __restrict__ da, int64_t chunks, FastDiv dcpc, FastDiv dWo, FastDiv dHo, int H, int W) {
     const int cpc = dcpc.d, Wo = dWo.d, Ho = dHo.d;
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
         const uint32_t opix = fdiv((uint32_t)idx, dcpc);
@@ -382,6 +384,15 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k][i] = (k == best) ? g[i] : 0.f;
+        }
+        if (add) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s8[8];
+                unpack8(add[b0 + offs[k]], s8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[k][i] += s8[i];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) da[b0 + offs[k]] = pack8(o[k]);
@@ -894,14 +905,15 @@ extern "C" int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, in
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp,
-                                       void* stream) {
+extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, const void* add, void* da, int32_t n_img, int32_t H, int32_t W,
+                                       int32_t Cp, void* stream) {
     if (!aligned16(a) || !aligned16(dp) || !aligned16(da) || n_img <= 0 || H < 2 || W < 2 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
+    if (add && (!aligned16(add) || (H % 2) || (W % 2))) return UCLSTM_E_BADARG;      // fused add: every input pixel is covered
     const int Ho = H / 2, Wo = W / 2;
     const int64_t chunks = (int64_t)n_img * Ho * Wo * (Cp / 8);
     if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(maxpool_bwd_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)dp,
-                       (uint4*)da, chunks, make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
+                       (const uint4*)add, (uint4*)da, chunks, make_fastdiv(Cp / 8), make_fastdiv(Wo), make_fastdiv(Ho), H, W);
     return UCLSTM_OK;
 }
 

@@ -157,6 +157,14 @@ class Down(nn.Module):
     def forward_nhwc(self, a: Tensor, groups: int = 1) -> Tensor:
         return self.net[1].forward_nhwc(ops.MaxPool2.apply(a), groups=groups)
 
+    def forward_nhwc_skip(self, a: Tensor, groups: int = 1):
+        """(block output, ``a`` for the skip connection): the caller must use the returned alias of ``a`` instead of ``a``, so
+        that the two gradients of ``a`` meet in one backward kernel (ops.MaxPool2Skip)."""
+        if not ops.POOL_SKIP:
+            return self.forward_nhwc(a, groups), a
+        p, skip = ops.MaxPool2Skip.apply(a)
+        return self.net[1].forward_nhwc(p, groups=groups), skip
+
     def forward(self, x):
         a = self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()))
         return ops.FromNHWC.apply(a, self.net[1].net[3].out_channels)
@@ -267,10 +275,10 @@ class TemporalUNetDualView(nn.Module):
     # -- internal NHWC encoder over n images in `groups` BatchNorm groups
     def _encode_nhwc(self, x: Tensor, time_major: bool, groups: int):
         x0 = self.inc.first_layer_nhwc(x, time_major, groups)
-        x1 = self.down1.forward_nhwc(x0, groups)
-        x2 = self.down2.forward_nhwc(x1, groups)
-        x3 = self.down3.forward_nhwc(x2, groups)
-        xb = self.bottleneck.forward_nhwc(x3, groups)
+        x1, x0 = self.down1.forward_nhwc_skip(x0, groups)
+        x2, x1 = self.down2.forward_nhwc_skip(x1, groups)
+        x3, x2 = self.down3.forward_nhwc_skip(x2, groups)
+        xb, x3 = self.bottleneck.forward_nhwc_skip(x3, groups)
         if self.use_attention:
             xb = self.attention.forward_nhwc(xb, self.base_ch * 16)
         return xb, (x3, x2, x1, x0)

@@ -338,6 +338,7 @@ def _fold_slabs(dwp: torch.Tensor) -> torch.Tensor:
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+POOL_SKIP = os.environ.get("UCLSTM_POOL_SKIP", "1") != "0"            # skip-connection gradient added inside max-pool backward
 DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
 GRAD_SIDE_HOOKS: list = []
 _WGRAD_OVERLAPPED = False      # True while a weight-gradient GEMM is being enqueued on the side stream
@@ -825,7 +826,38 @@ class MaxPool2(torch.autograd.Function):
         dp = dp.contiguous()
         N, H, W, Cp = a.shape
         da = torch.zeros_like(a) if (H % 2 or W % 2) else torch.empty_like(a)
-        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), _p(da), N, H, W, Cp, _stream()), "maxpool2_bwd")
+        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), None, _p(da), N, H, W, Cp, _stream()), "maxpool2_bwd")
+        return da
+
+
+class MaxPool2Skip(torch.autograd.Function):
+    """MaxPool2d(2) of ``a`` plus ``a`` itself as a second output (the skip connection): in the UNet every encoder output is
+    used twice (train/unet.py:166-169), so its gradient is a sum of two tensors -- added inside the max-pool backward kernel
+    instead of by autograd's separate elementwise add (one read + one write of the full-resolution tensor less)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        _dev(a, BF16, "activation")
+        N, H, W, Cp = a.shape
+        p = torch.empty((N, H // 2, W // 2, Cp), dtype=BF16, device=a.device)
+        L.check(L.lib.uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(a)
+        return p, a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, dp, dskip):
+        (a,) = ctx.saved_tensors
+        N, H, W, Cp = a.shape
+        if dp is None:
+            return dskip
+        dp = dp.contiguous()
+        odd = bool(H % 2 or W % 2)
+        da = torch.zeros_like(a) if odd else torch.empty_like(a)
+        fused = dskip is not None and not odd
+        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), _p(dskip.contiguous()) if fused else None, _p(da), N, H, W, Cp, _stream()),
+                "maxpool2_bwd")
+        if dskip is not None and not fused:
+            da = da + dskip
         return da
 
 
