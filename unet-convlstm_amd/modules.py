@@ -105,6 +105,20 @@ class ConvLSTM(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # UNet blocks (reference train/unet.py:66-107)
 # ---------------------------------------------------------------------------------------------
+# BatchNorm's ``num_batches_tracked`` counters: 18 scalar int64 adds per model forward, 5 us each on the GPU.  The full model
+# collects them here and bumps them with one multi-tensor add at the end of its forward (stand-alone blocks add directly).
+_DEFERRED_COUNTERS: Optional[list] = None
+
+
+def _flush_counters(pending: list) -> None:
+    by_inc: dict = {}
+    for t, inc in pending:
+        by_inc.setdefault(inc, []).append(t)
+    with torch.no_grad():
+        for inc, ts in by_inc.items():
+            torch._foreach_add_(ts, inc)
+
+
 class DoubleConv(nn.Module):
     """Reference train/unet.py:66-75: (conv3x3 + BN + ReLU) x 2, ``self.net`` indices 0,1,3,4 hold the parameters."""
 
@@ -121,7 +135,10 @@ class DoubleConv(nn.Module):
         a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += groups      # the reference calls BN once per timestep
+            if _DEFERRED_COUNTERS is not None:
+                _DEFERRED_COUNTERS.append((bn.num_batches_tracked, groups))      # one multi-tensor add per model forward
+            else:
+                bn.num_batches_tracked += groups      # the reference calls BN once per timestep
         return a
 
     def forward_nhwc(self, x0: Tensor, x1: Optional[Tensor] = None, c_valid=None, off=(0, 0), groups: int = 1,
@@ -291,6 +308,17 @@ class TemporalUNetDualView(nn.Module):
         return f(xb, c * 16), (f(x3, c * 8), f(x2, c * 4), f(x1, c * 2), f(x0, c))
 
     def forward(self, x_seq, state=None):
+        global _DEFERRED_COUNTERS
+        pending, _DEFERRED_COUNTERS = [], None
+        _DEFERRED_COUNTERS = pending
+        try:
+            return self._forward(x_seq, state)
+        finally:
+            _DEFERRED_COUNTERS = None
+            if pending:
+                _flush_counters(pending)
+
+    def _forward(self, x_seq, state=None):
         B, T, Cc, H, W = x_seq.shape
         c = self.base_ch
         # encoder: all T timesteps as one batch of T*B images (time-major), BN statistics per timestep
