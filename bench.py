@@ -19,6 +19,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
-TRAIN_GFLOP_PER_FRAME = {(64, True, 64): 39.79, (32, False, 64): 6.33, (64, True, 128): 159.17}
+TRAFFIC_FILE = "round1_hbm_traffic.json"
+TRAFFIC_NOTE = (f"committed PMC passes (profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of "
+                "this command, gfx950 correction applied); NOT measured in this run")
+TRAIN_GFLOP_PER_FRAME = {(64, True, 64): 39.79, (32, False, 64): 6.33, (64, True, 128): 159.17, (32, False, 128): 25.33,
+                         (64, True, 256): 636.67}
 
 
 def parse():
@@ -51,11 +57,55 @@ def parse():
                     help="keep weight-gradient GEMMs on the main stream for the whole run (the profile run: kernel durations "
                          "in a rocprofv3 trace are then free of side-stream overlap and agree with the roofline leg)")
     ap.add_argument("--dump-launches", action="store_true", help="per-shape table of the instrumented step (stderr)")
+    ap.add_argument("--bf16-buckets", action="store_true", help="FlatDDP exchanges gradients as bf16 (half the bytes over xGMI)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, rendezvous over gloo on the CPU, report what every rank saw and exit (no GPU work): "
+                         "the CPU test of the launch contract")
     return ap.parse_args()
 
 
-def cpu_baseline(base_ch: int, skip: bool, size: int):
-    """Oracle (CPU restatement, kind 'port') training step on the host cores, bounded sample."""
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a) -> int:
+    """``python bench.py --gpus N`` without torchrun: start the N ranks HERE, as fresh child processes, before this process
+    has made any HIP call (a process that has initialised the GPU must never exec or fork into another GPU program), and
+    return the launcher's exit code.  The children are this same script under ``torch.distributed.run``; rank 0 prints the
+    JSON line on the inherited stdout."""
+    if not a.dry_launch:
+        have = torch.cuda.device_count()          # counts devices without creating a HIP context
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    log("launching " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(a, world: int, rank: int) -> None:
+    """Every rank joins a gloo group on the CPU and reports (rank, WORLD_SIZE, LOCAL_RANK); rank 0 prints them."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "world_size": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+        dist.destroy_process_group()
+    else:
+        seen = [{"rank": 0, "world_size": 1, "local_rank": 0}]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": a.gpus, "ranks": seen}), flush=True)
+
+
+def cpu_baseline(base_ch: int, skip: bool, size: int, seq: int):
+    """Oracle (CPU restatement, kind 'port') training step on the host cores, bounded sample (the same
+    synthetic batch shrunk to B=4 at 64x64 / B=2 above, 1 warm-up + 3 timed steps, best and median)."""
     from oracle import unet_oracle as O
     import unet_convlstm_amd as U
     cores = os.cpu_count() or 1
@@ -68,18 +118,24 @@ def cpu_baseline(base_ch: int, skip: bool, size: int):
     torch.manual_seed(0)
     m = U.TemporalUNetDualView(1, 1, base_ch=base_ch, use_skip_lstm=skip)          # parameter container only (CPU)
     p = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    B, T = 4, 8          # ~12 s of CPU work on 16 threads
-    log(f"cpu_baseline: oracle training step on {cores} host threads, B={B} T={T} ...")
+    B, T = (4 if size <= 64 else 2), seq
+    if size > 128:
+        B, T = 1, min(seq, 4)
+    log(f"cpu_baseline: oracle training step on {cores} host threads, B={B} T={T}, 1 warm-up + 3 timed ...")
     g = torch.Generator().manual_seed(1)
     x = torch.rand((B, T, 2, size, size), generator=g)
     y = torch.rand((B, T, 1, size, size), generator=g) * 2 - 1
-    O.train_step({k: v for k, v in p.items()}, x[:1, :1], y[:1, :1], None, False)      # thread-pool / allocator warm-up
-    t0 = time.perf_counter()
-    O.train_step(p, x, y, None, False)
-    dt = time.perf_counter() - t0
-    return {"value": round(B * T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 oracle training step (fp32 PyTorch eager CPU), B={B} T={T} {size}x{size}, base_ch={base_ch}, "
-                      f"skip_lstm={skip}; {dt:.1f} s"}
+    O.train_step(dict(p), x[:, :2], y[:, :2], None, False)      # warm-up step (thread pool, allocator) on a 2-frame prefix
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.train_step(dict(p), x, y, None, False)
+        times.append(time.perf_counter() - t0)
+        log(f"cpu_baseline: step {len(times)}/3 {times[-1]:.1f} s")
+    best, med = min(times), sorted(times)[1]
+    return {"value": round(B * T / best, 3), "median": round(B * T / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle training step (fp32 PyTorch eager CPU), B={B} T={T} {size}x{size}, base_ch={base_ch}, "
+                      f"skip_lstm={skip}; 1 warm-up + 3 timed steps, best {best:.1f} s, median {med:.1f} s"}
 
 
 def log(msg):
@@ -118,8 +174,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a))             # nothing has touched the GPU yet in this process
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_launch:
+        return dry_launch(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local)
@@ -144,7 +204,7 @@ def main():
         return rollout_bench(a, U, dev, skip)
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
     opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
-    ddp = U.FlatDDP(model, opt.flat) if (world > 1 or a.force_ddp) else None
+    ddp = U.FlatDDP(model, opt.flat, grad_dtype=torch.bfloat16 if a.bf16_buckets else None) if (world > 1 or a.force_ddp) else None
     data = U.SyntheticSequences(a.batch, a.seq, a.size, a.size, seed=1 + rank, kind="uniform", device=dev)
     x, y = data.x, data.y
 
@@ -214,7 +274,7 @@ def main():
             # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
             # --pmc WRITE_SIZE in separate runs of this same command, gfx950 correction applied: tools/pmc_traffic.py)
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
             if (a.base_ch, skip, a.size, a.seq, a.batch) == (64, True, 64, 20, 32) and os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath))["kernels"][dom]["hbm_bytes_per_launch"]
@@ -222,7 +282,8 @@ def main():
                     traffic = None
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/round1_hbm_traffic.json)", "launches": n, "timing": "HIP events, one serialised step (side stream off)",
+                    "traffic_unit": "HBM bytes per launch", "traffic_source": TRAFFIC_NOTE if traffic is not None else None,
+                    "launches": n, "timing": "HIP events, one serialised step (side stream off)",
                     "avg_launch_ms": round(ms / n, 4),
                     "all": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
                             for k, v in agg.items()}}
@@ -240,6 +301,7 @@ def main():
             "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) train step, "
                                    f"{a.size}x{a.size} seq-{a.seq}, per-GPU batch {a.batch}, AdamW+clip",
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "final_loss": round(lossv, 5),
         }
         if gf is not None:
@@ -248,7 +310,7 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size)
+            out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size, a.seq)
         print(json.dumps(out), flush=True)
     if world > 1 or a.force_ddp:
         dist.destroy_process_group()

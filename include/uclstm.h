@@ -187,6 +187,8 @@ int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, v
 /* From the conv epilogue's partial sums build, per (group, channel): scale = gamma*rstd,
  * shift = beta - mean*scale, mean, rstd; then update running_mean/var with momentum 0.1 and
  * the unbiased variance, once per group IN ORDER (the reference calls BN once per timestep).
+ * momentum < 0 means BatchNorm2d(momentum=None): cumulative average, group g uses the factor
+ * 1/(-momentum + g), i.e. pass -(num_batches_tracked + 1).
  * `stats` is CONSUMED (its tile-0 slots are overwritten with mean/variance).  stats == NULL:
  * evaluation mode, scale/shift from the running statistics (groups = 1), nothing is updated. */
 int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,

@@ -93,9 +93,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
                 const double var = (double)mv.y;
                 mu = mv.x;
                 rs = (float)(1.0 / sqrt(var + (double)eps));
-                // running stats: one momentum step per group, in group order (train/unet.py:179,:196)
-                rm = (1.f - momentum) * rm + momentum * mu;
-                rv = (1.f - momentum) * rv + momentum * (float)(var * unbias);
+                // running stats: one momentum step per group, in group order (train/unet.py:179,:196).  momentum < 0 encodes
+                // BatchNorm2d(momentum=None): cumulative average, factor 1/(batches tracked so far + 1), -momentum = that count
+                // for the first group
+                const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)g);
+                rm = (1.f - mom) * rm + mom * mu;
+                rv = (1.f - mom) * rv + mom * (float)(var * unbias);
             } else {
                 mu = rm;
                 rs = 1.0f / sqrtf(rv + eps);

@@ -22,10 +22,16 @@ from .optim import FlatParams
 
 class FlatDDP:
     def __init__(self, module: torch.nn.Module, flat: FlatParams, bucket_mb: float = 64.0, process_group=None,
-                 broadcast: bool = True, first_bucket_mb: float = 1.0):
+                 broadcast: bool = True, first_bucket_mb: float = 1.0, grad_dtype: Optional[torch.dtype] = None):
+        """``grad_dtype=torch.bfloat16``: exchange the gradients as bf16 (half the bytes per link; every bucket is cast into
+        a staging buffer, all-reduced there and cast back into the f32 gradient buffer before the optimiser step)."""
         if not dist.is_initialized():
             raise RuntimeError("FlatDDP: torch.distributed is not initialised")
+        if grad_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("FlatDDP: grad_dtype must be None / torch.float32 / torch.bfloat16")
         self.module, self.flat, self.pg = module, flat, process_group
+        self.grad_dtype = None if grad_dtype in (None, torch.float32) else grad_dtype
+        self._stage = torch.empty_like(flat.flat_g, dtype=self.grad_dtype) if self.grad_dtype is not None else None
         self.world = dist.get_world_size(process_group)
         # RCCL averages inside the collective; gloo (CPU tests) has no AVG and gets an explicit scale in finalize()
         self._op = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else dist.ReduceOp.SUM
@@ -74,16 +80,41 @@ class FlatDDP:
         # weight gradients that the operators accumulate on their side stream never pass through autograd's accumulator:
         # they announce themselves through ops.GRAD_SIDE_HOOKS (called with the side stream current)
         self._index_of = {id(p): i for i, p in enumerate(flat.params)}
-        if flat.flat_g.is_cuda:
-            from . import ops
-            self._side_hook = lambda param: self._on_ready(self._index_of[id(param)]) if id(param) in self._index_of else None
-            ops.GRAD_SIDE_HOOKS.append(self._side_hook)
+        self._uses = [0] * len(flat.params)          # uses reported by the operators' forward passes since reset()
+        self._seen = [0] * len(flat.params)          # side announcements received since reset()
+        self._done = [False] * len(flat.params)
+        self._sync = True
+        from . import ops
+        self._side_hook = lambda param: self._on_ready(self._index_of[id(param)], True) if id(param) in self._index_of else None
+        self._use_hook = self._on_use
+        ops.GRAD_SIDE_HOOKS.append(self._side_hook)
+        ops.USE_HOOKS.append(self._use_hook)
         self._main_stream = None
         self.reset()
 
-    def _on_ready(self, i: int) -> None:
+    def _on_use(self, param) -> None:
+        i = self._index_of.get(id(param))
+        if i is not None and self._sync:
+            self._uses[i] += 1
+
+    def _on_ready(self, i: int, side: bool = False) -> None:
+        """Gradient ``i`` has been produced.  ``side``: announced by an operator that wrote ``.grad`` itself -- once per USE
+        of the parameter, so the parameter is complete only after as many announcements as forward reported uses;
+        autograd's own accumulator (``side=False``) fires once per backward pass, after all uses."""
+        if not self._sync:
+            return
+        if side:
+            self._seen[i] += 1
+            expected = max(1, self._uses[i])
+            assert self._seen[i] <= expected, f"FlatDDP: parameter {i} announced {self._seen[i]} gradients for {expected} uses"
+            if self._seen[i] < expected:
+                return
+        if self._done[i]:
+            return
+        self._done[i] = True
         bi = self.bucket_of[i]
         self._pending[bi] -= 1
+        assert self._pending[bi] >= 0, f"FlatDDP: bucket {bi} completed more gradients than it holds"
         if self._pending[bi] == 0:
             self._launch(bi)
 
@@ -92,11 +123,30 @@ class FlatDDP:
             self._on_ready(i)
         return hook
 
+    class _NoSync:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.prev, self.owner._sync = self.owner._sync, False
+
+        def __exit__(self, *exc):
+            self.owner._sync = self.prev
+
+    def no_sync(self):
+        """Gradient accumulation: forward/backward passes inside ``with ddp.no_sync():`` neither count uses nor launch
+        collectives; the gradients of the last pass (outside the context) are exchanged with everything accumulated."""
+        return FlatDDP._NoSync(self)
+
     def _launch(self, bi: int) -> None:
         lo, hi = self.ranges[bi]
         g = self.flat.flat_g
         if not g.is_cuda:
-            self._handles[bi] = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            buf = g[lo:hi]
+            if self._stage is not None:
+                buf = self._stage[lo:hi]
+                buf.copy_(g[lo:hi])
+            self._handles[bi] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             return
         # a bucket mixes gradients produced on the main stream (autograd accumulation) and on the operators' side stream
         # (weight-gradient GEMMs).  The collective is enqueued from a third, kernel-less stream that waits for both, so
@@ -110,12 +160,20 @@ class FlatDDP:
         if cur != main:
             launch.wait_stream(cur)
         with torch.cuda.stream(launch):
-            self._handles[bi] = dist.all_reduce(g[lo:hi], op=self._op, group=self.pg, async_op=True)
+            buf = g[lo:hi]
+            if self._stage is not None:
+                buf = self._stage[lo:hi]
+                buf.copy_(g[lo:hi])                     # f32 -> bf16 on the launch stream, right before the collective
+            self._handles[bi] = dist.all_reduce(buf, op=self._op, group=self.pg, async_op=True)
 
     def reset(self) -> None:
-        """Call before each backward (after zero_grad), on the stream that will run the backward pass."""
+        """Call once per optimisation step BEFORE the forward pass (after zero_grad), on the stream that will run the step:
+        the operators report parameter uses during forward."""
         self._pending = [len(b) for b in self.buckets]
         self._handles = [None] * len(self.buckets)
+        self._uses = [0] * len(self.flat.params)
+        self._seen = [0] * len(self.flat.params)
+        self._done = [False] * len(self.flat.params)
         if self.flat.flat_g.is_cuda:
             self._main_stream = torch.cuda.current_stream(self.flat.flat_g.device)
 
@@ -127,6 +185,8 @@ class FlatDDP:
                 self._launch(bi)
         for h in self._handles:
             h.wait()                   # the current stream waits for the collective's stream (no host block on GPUs)
+        if self._stage is not None:
+            self.flat.flat_g.copy_(self._stage)          # bf16 -> f32, one pass over the gradient buffer
         if self.world > 1 and self._op == dist.ReduceOp.SUM:
             self.flat.flat_g.mul_(1.0 / self.world)
 
@@ -138,7 +198,9 @@ class FlatDDP:
             from . import ops
             if self._side_hook in ops.GRAD_SIDE_HOOKS:
                 ops.GRAD_SIDE_HOOKS.remove(self._side_hook)
-            self._side_hook = None
+            if self._use_hook in ops.USE_HOOKS:
+                ops.USE_HOOKS.remove(self._use_hook)
+            self._side_hook = self._use_hook = None
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)

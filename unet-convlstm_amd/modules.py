@@ -131,7 +131,14 @@ class DoubleConv(nn.Module):
 
     def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False):
         training = self.training or not bn.track_running_stats
-        mom = 0.1 if bn.momentum is None else bn.momentum
+        if bn.momentum is not None:
+            mom = bn.momentum
+        elif training and bn.num_batches_tracked is not None:
+            # momentum=None is PyTorch's cumulative moving average (factor 1/num_batches_tracked after the bump); the counter
+            # lives on the device, so this rare mode (no reference script uses it) costs one host read per stage
+            mom = -float(int(bn.num_batches_tracked) + 1)
+        else:
+            mom = 0.0
         a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
         if training and bn.num_batches_tracked is not None:

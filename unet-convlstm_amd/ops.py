@@ -54,11 +54,18 @@ PROFILE: Optional[list] = None
 # Optional record of which forward-family kernel each launch takes (uclstm_igemm_fwd_shape: 0 / 1 per-tap shapes, 2 patch loop,
 # 3 ring kernel): tests set it to a list to assert that a parity case exercised the kernel it is meant for.
 SHAPE_LOG: Optional[list] = None
+# Same, as (epilogue, shape) pairs -- epilogue 0 store, 1 fused ConvLSTM cell, 2 split-K partial tiles: the BASELINE-shape
+# parity tests assert that the fused-cell, split-K and patch kernels the benchmark runs were the ones compared.
+KERNEL_LOG: Optional[list] = None
 
 
 def _log_shape(d) -> None:
-    if SHAPE_LOG is not None:
-        SHAPE_LOG.append(int(L.lib.uclstm_igemm_fwd_shape(C.byref(d))))
+    if SHAPE_LOG is not None or KERNEL_LOG is not None:
+        shp = int(L.lib.uclstm_igemm_fwd_shape(C.byref(d)))
+        if SHAPE_LOG is not None:
+            SHAPE_LOG.append(shp)
+        if KERNEL_LOG is not None:
+            KERNEL_LOG.append((int(d.epi), shp))
 
 
 def _timed(kind: str, flops: float, launch, note: str = "") -> None:
@@ -217,15 +224,46 @@ def convt_dgrad_pack_desc(Ci: int, Co: int) -> L.PackDesc:
     return d
 
 
-# Inference-time panel cache, OFF unless a caller that owns frozen weights turns it on (streaming.StreamingPredictor):
-# removes ~50 pack launches per forward from a rollout.  It cannot be automatic: the fused optimiser updates parameters
-# through raw pointers, which does not bump tensor versions, so only the owner knows the weights are frozen.
-CACHE_PANELS = False
-_PANEL_CACHE: dict = {}
+# Inference-time panel cache.  There is no module-global cache: a caller that owns frozen weights (streaming.
+# StreamingPredictor) creates a ``PanelCache`` and makes it current around its forward calls; the panels live exactly as long
+# as that object (a captured HIP graph has their addresses baked in, so they must not be freed under it).  Entries are
+# validated by the weight tensor's version AND by ``WEIGHTS_EPOCH``, which the fused optimiser bumps on every step: it updates
+# parameters through raw pointers, which does not change tensor versions.
+WEIGHTS_EPOCH = 0
 
 
-def clear_panel_cache() -> None:
-    _PANEL_CACHE.clear()
+def weights_changed() -> None:
+    """Called by code that rewrites parameter storage behind autograd's back (optim.FusedAdamW.step)."""
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
+class PanelCache:
+    """Packed panels of frozen weights, keyed by (storage address, element offset, pack descriptor)."""
+
+    def __init__(self):
+        self.entries: dict = {}
+        self.epoch = WEIGHTS_EPOCH
+
+    def stale(self) -> bool:
+        return self.epoch != WEIGHTS_EPOCH
+
+    def clear(self) -> None:
+        self.entries.clear()
+        self.epoch = WEIGHTS_EPOCH
+
+    def __enter__(self):
+        global _ACTIVE_CACHE
+        self._prev = _ACTIVE_CACHE
+        _ACTIVE_CACHE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE_CACHE
+        _ACTIVE_CACHE = self._prev
+
+
+_ACTIVE_CACHE: Optional[PanelCache] = None
 
 
 # Look-ahead packing for training steps (engine.train_step): the weights only change in the optimiser step, so every panel of
@@ -285,17 +323,19 @@ def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0) -> tor
             torch.cuda.current_stream(w.device).wait_event(hit[1])
             return hit[0]
         key = None
-    if CACHE_PANELS:
+    cache = _ACTIVE_CACHE
+    if cache is not None:
+        if cache.stale():
+            raise L.UclstmError("PanelCache: the weights changed (optimiser step) while a panel cache was current; its owner "
+                                "must drop it first (StreamingPredictor does so in step())")
         key = (w.data_ptr(), elem_offset, bytes(desc))
-        hit = _PANEL_CACHE.get(key)
+        hit = cache.entries.get(key)
         if hit is not None and hit[0] == w._version:
             return hit[1]
     wp = torch.empty((desc.N, desc.Ktot), dtype=BF16, device=w.device)
     L.check(L.lib.uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * elem_offset), _p(wp), _stream()), "pack_weights")
     if key is not None:
-        if len(_PANEL_CACHE) > 512:
-            _PANEL_CACHE.clear()
-        _PANEL_CACHE[key] = (w._version, wp)
+        cache.entries[key] = (w._version, wp)
     return wp
 
 
@@ -458,12 +498,65 @@ def grad_written(param: torch.Tensor) -> None:
         hook(param)
 
 
+# A parameter whose gradient is written outside autograd announces itself once per USE (autograd's own accumulator fires
+# once per backward pass, however often the parameter was used).  Operators therefore report every use in forward, so that
+# a data-parallel wrapper knows how many announcements complete a parameter -- a module called twice before one backward
+# (reference-style per-timestep loops over ConvLSTMCell, two forwards under one loss) must not release its bucket early.
+USE_HOOKS: list = []
+
+
+def note_use(*params) -> None:
+    if USE_HOOKS:
+        for p in params:
+            if p is not None:
+                for hook in USE_HOOKS:
+                    hook(p)
+
+
 # ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
+# A single GEMM launch addresses every operand through a 32-bit buffer descriptor whose bit 31 means "outside the tensor"
+# (that is how padding is free), so one launch sees at most ~2 GiB of each tensor.  The reference, which runs one timestep
+# at a time, has no such limit: batched launches over n_img = T*B images are therefore cut into image ranges here -- on
+# BatchNorm-group (timestep) boundaries when the launch also produces statistics, whose rows are per group anyway.
+LAUNCH_BYTES_LIMIT = (1 << 31) - (1 << 23)
+
+
+def _img_chunks(n_img: int, groups: int, bytes_per_img: int, what: str, whole_groups: bool = False) -> List[Tuple[int, int]]:
+    """Image ranges [i0, i1) of at most LAUNCH_BYTES_LIMIT bytes each; with ``whole_groups`` (the launch writes per-group
+    BatchNorm partial sums) a range is a whole number of groups of n_img/groups images."""
+    if n_img * bytes_per_img < LAUNCH_BYTES_LIMIT:
+        return [(0, n_img)]
+    ipg = n_img // groups
+    unit = ipg if whole_groups else 1
+    per = ((LAUNCH_BYTES_LIMIT - 1) // (bytes_per_img * unit)) * unit
+    if per < unit or per == 0:
+        raise L.UclstmError(f"{what}: one {'BatchNorm group' if whole_groups else 'image'} of this tensor ({unit} image(s) x "
+                            f"{bytes_per_img} bytes) exceeds the {LAUNCH_BYTES_LIMIT}-byte range a single launch can address; "
+                            "use a smaller per-GPU batch")
+    return [(i, min(n_img, i + per)) for i in range(0, n_img, per)]
+
+
+def _bytes_per_img(t: torch.Tensor) -> int:
+    return t[0].numel() * t.element_size()
+
+
 def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, segs, *, ktap: int, scale: int = 1,
                 pad: int = 0, groups: int = 1, bias=None, col_scale=None, col_shift=None, relu: bool = False, stats=None) -> None:
-    """segs: list of (tensor, n_begin, n_end, c_off, scale, oy, ox)."""
+    """segs: list of (tensor, n_begin, n_end, c_off, scale, oy, ox).  ``stats``: [groups, tiles_per_group, N, 2]."""
+    per_img = max([_bytes_per_img(sv.t) for sv in srcs] + [_bytes_per_img(sg[0]) for sg in segs])
+    chunks = _img_chunks(n_img, groups, per_img, "igemm_fwd(store)", whole_groups=stats is not None)
+    if len(chunks) > 1:
+        ipg = n_img // groups
+        for i0, i1 in chunks:
+            sub_src = [SrcView(sv.t[i0:i1], sv.offY, sv.offX) for sv in srcs]
+            sub_seg = [(sg[0][i0:i1],) + tuple(sg[1:]) for sg in segs]
+            sub_stats = None if stats is None else stats[i0 // ipg:i1 // ipg]
+            igemm_store(sub_src, wp, out_hw, i1 - i0, sub_seg, ktap=ktap, scale=scale, pad=pad,
+                        groups=(i1 - i0) // ipg if stats is not None else 1, bias=bias, col_scale=col_scale, col_shift=col_shift,
+                        relu=relu, stats=sub_stats)
+        return
     d = L.IgemmDesc()
     d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], groups
     d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
@@ -547,30 +640,41 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
 
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
                 pad: int = 0) -> torch.Tensor:
+    """Weight-gradient GEMM; returns the f32 panel gradient as pixel-range slabs [splits, N, Ktot] (the unpack adds them).
+    Operands beyond the single-launch byte range are processed as image ranges, each range contributing its own slabs."""
     dev = srcs[0].t.device
-    d = L.WgradDesc()
-    d.n_img, d.H, d.W = n_img, out_hw[0], out_hw[1]
-    d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
-    for i, s in enumerate(srcs):
-        s.fill(d.src[i])
-    d.N, d.Ktot = N, Ktot
-    d.nseg = len(dy_segs)
-    for i, sg in enumerate(dy_segs):
-        _fill_seg(d.seg[i], *sg)
+    per_img = max([_bytes_per_img(sv.t) for sv in srcs] + [_bytes_per_img(sg[0]) for sg in dy_segs])
+    chunks = _img_chunks(n_img, 1, per_img, "igemm_wgrad")
+    descs = []
+    for i0, i1 in chunks:
+        d = L.WgradDesc()
+        d.n_img, d.H, d.W = i1 - i0, out_hw[0], out_hw[1]
+        d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
+        for i, sv in enumerate(srcs):
+            (sv if len(chunks) == 1 else SrcView(sv.t[i0:i1], sv.offY, sv.offX)).fill(d.src[i])
+        d.N, d.Ktot = N, Ktot
+        d.nseg = len(dy_segs)
+        for i, sg in enumerate(dy_segs):
+            _fill_seg(d.seg[i], *(sg if len(chunks) == 1 else (sg[0][i0:i1],) + tuple(sg[1:])))
+        # slab mode: every pixel range stores its partial panel into its own slab (no float atomics, nothing to zero);
+        # the library picks the range count for its tile shape and the 256 CUs, uclstm_unpack_wgrad adds the slabs
+        d.splits, d.accumulate, d.slab = 0, 1, N * Ktot
+        d.overlapped = int(_WGRAD_OVERLAPPED)          # on the side stream: the plan that interferes least with the main stream
+        splits = int(L.lib.uclstm_igemm_wgrad_splits(C.byref(d)))
+        if splits < 1:
+            raise L.UclstmError(f"igemm_wgrad: bad descriptor (code {splits})")
+        d.splits = splits
+        descs.append(d)
+    total = sum(d.splits for d in descs)
+    dwp = torch.empty((total, N, Ktot), dtype=F32, device=dev)
     taps = ktap * ktap
-    # slab mode: every pixel range stores its partial panel into its own slab (no float atomics, nothing to zero);
-    # the library picks the range count for its tile shape and the 256 CUs, uclstm_unpack_wgrad adds the slabs
-    d.splits, d.accumulate, d.slab = 0, 1, N * Ktot
-    d.overlapped = int(_WGRAD_OVERLAPPED)          # on the side stream: the plan that interferes least with the main stream
-    splits = int(L.lib.uclstm_igemm_wgrad_splits(C.byref(d)))
-    if splits < 1:
-        raise L.UclstmError(f"igemm_wgrad: bad descriptor (code {splits})")
-    dwp = torch.empty((splits, N, Ktot), dtype=F32, device=dev)
-    d.splits = splits
-    d.dwp = dwp.data_ptr()
-    flops = 2.0 * n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
-    _timed("igemm_wgrad", flops, lambda: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={splits}")
+    at = 0
+    for d in descs:
+        d.dwp = dwp[at].data_ptr()
+        at += d.splits
+        flops = 2.0 * d.n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
+        _timed("igemm_wgrad", flops, lambda d=d: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
+               f"M={d.n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
     return dwp
 
 
@@ -719,8 +823,9 @@ class ConvBNReLU(torch.autograd.Function):
         wp = pack_weights(pd, weight)
         bp = pack_bias(pd, bias) if bias is not None else None
         out = torch.empty((n_img, H, W, Cop), dtype=BF16, device=dev)
-        ppg = (n_img // groups) * H * W
+        need_bw = any(ctx.needs_input_grad)
         if training:
+            ppg = (n_img // groups) * H * W
             tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups, Cop)
             stats = torch.empty((groups, tpg, Cop, 2), dtype=F32, device=dev)
             z = out
@@ -733,6 +838,21 @@ class ConvBNReLU(torch.autograd.Function):
             L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
                     "bn_apply_relu")
             ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
+            note_use(weight, gamma, beta, bias)
+        elif need_bw:
+            # evaluation-mode statistics WITH a backward pass (fine-tuning through frozen BatchNorm): keep the pre-BN conv
+            # output like the training path does, normalise with the running statistics as one group
+            groups = 1
+            z = out
+            igemm_store(srcs, wp, (H, W), n_img, [(z, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp)
+            par = torch.empty((4, 1, Cop), dtype=F32, device=dev)
+            L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                             momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _stream()), "bn_finalize(eval)")
+            a = torch.empty_like(z)
+            L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, n_img * H * W, Cop, _stream()),
+                    "bn_apply_relu")
+            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
+            note_use(weight, gamma, beta, bias)
         else:
             par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -748,8 +868,6 @@ class ConvBNReLU(torch.autograd.Function):
     def backward(ctx, da):
         x0, x1, weight, z, par, gamma, beta, bias = ctx.saved_tensors
         c_valid, off, groups, training, im2col, Co, Ci_total, has_bias = ctx.cfg
-        if not training:
-            raise L.UclstmError("backward through eval-mode BatchNorm is not implemented (reference trains in train mode)")
         da = da.contiguous()
         n_img, H, W, Cop = z.shape
         dev = z.device
@@ -759,9 +877,14 @@ class ConvBNReLU(torch.autograd.Function):
         L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
                                            _stream()), "bn_bwd_reduce")
         dz = torch.empty_like(z)
-        L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums), _p(dz), pixels, ppg,
+        # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
+        # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
+        sums_dz = sums if training else torch.zeros_like(sums)
+        L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz), pixels, ppg,
                                           Cop, _stream()), "bn_bwd_apply")
-        # conv bias feeds BatchNorm, which removes any per-channel constant: its gradient is analytically 0
+        # training: the conv bias feeds BatchNorm, which removes any per-channel constant -- its gradient is analytically 0.
+        # With frozen statistics it is the column sum of dz.
+        bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
         g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
         if g_gamma is not None and g_beta is not None:
             # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates)
@@ -771,15 +894,18 @@ class ConvBNReLU(torch.autograd.Function):
             grad_written(beta)
             dbias = None
             if has_bias:
-                if direct_grad(bias) is not None:
-                    grad_written(bias)                          # += 0
+                g_bias = direct_grad(bias)
+                if g_bias is not None:
+                    if not training:
+                        g_bias.add_(bias_grad())
+                    grad_written(bias)                          # training: += 0
                 else:
-                    dbias = torch.zeros((Co,), dtype=F32, device=dev)
+                    dbias = bias_grad()
         else:
             tot = sums.sum(dim=0)
             dbeta = tot[:Co, 0].contiguous()
             dgamma = tot[:Co, 1].contiguous()
-            dbias = torch.zeros((Co,), dtype=F32, device=dev) if has_bias else None
+            dbias = bias_grad() if has_bias else None
 
         dy_seg = [(dz, 0, Cop, 0, 1, 0, 0)]
         if im2col:
@@ -879,6 +1005,8 @@ class ConvT2x2(torch.autograd.Function):
         igemm_store([SrcView(x)], wp, (h, w), N, segs, ktap=1, pad=0, bias=bp)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if any(ctx.needs_input_grad):
+            note_use(weight)
         return u
 
     @staticmethod
@@ -985,6 +1113,7 @@ class ConvLSTMSeq(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates)
             ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
+            note_use(weight)
         return h_hist[1:], c_hist[T]
 
     @staticmethod

@@ -72,6 +72,25 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 - signature parity with torch
         self.flat.zero_grad()
 
+    # The moments and the bias-correction step live in flat buffers outside ``Optimizer.state``: carry them explicitly,
+    # otherwise a save / load / resume would silently restart Adam.
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "step": int(self.step_count),
+                       "numel": int(self.flat.numel)}
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        fused = state_dict.get("fused")
+        if fused is None:
+            raise ValueError("FusedAdamW.load_state_dict: no 'fused' entry (not a FusedAdamW state_dict)")
+        if int(fused["numel"]) != self.flat.numel:
+            raise ValueError(f"FusedAdamW.load_state_dict: {fused['numel']} parameters saved, {self.flat.numel} here")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "fused"})
+        self.m.copy_(fused["exp_avg"])
+        self.v.copy_(fused["exp_avg_sq"])
+        self.step_count = int(fused["step"])
+
     @torch.no_grad()
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the last clipped step's gradients (device scalar, f64)."""
@@ -95,4 +114,6 @@ class FusedAdamW(torch.optim.Optimizer):
                                         C.c_void_p(f.flat_g.data_ptr()), f.numel, sq,
                                         float(self.max_grad_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                         float(g["eps"]), float(g["weight_decay"]), self.step_count, _stream()), "adamw_step")
+        from . import ops
+        ops.weights_changed()          # raw-pointer update: tensor versions do not move, panel caches must be told
         return None

@@ -23,13 +23,23 @@ class StreamingPredictor:
         self.reset()
 
     def reset(self) -> None:
-        """Forget the recurrent state (next frame starts a new sequence) and any captured graph."""
+        """Forget the recurrent state (next frame starts a new sequence), any captured graph and the packed panels."""
         self._state: Optional[dict] = None
+        self._shape = None
+        self._drop_graph_and_panels()
+
+    def _drop_graph_and_panels(self) -> None:
+        # order matters: the captured graph has the panels' addresses baked in, so it goes first; the panels are owned by
+        # this predictor's cache (never by a module-global one) and die with it
         self._graph = None
         self._static_x = None
         self._static_y = None
-        self._shape = None
         self._eager_steps = 0
+        self._panels = ops.PanelCache()
+        self._wsig = self._weights_signature()
+
+    def _weights_signature(self):
+        return (ops.WEIGHTS_EPOCH, sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.model.buffers()))
 
     # ---- state helpers: fixed buffers so that a captured graph can update them in place ----
     def _zero_state(self, x_t: torch.Tensor) -> dict:
@@ -67,9 +77,13 @@ class StreamingPredictor:
                 raise ValueError("StreamingPredictor: frame shape changed; call reset() first")
             self._shape = tuple(x_t.shape)
             self._state = self._zero_state(x_t)
-        old_cache = ops.CACHE_PANELS
-        ops.CACHE_PANELS = True                       # weights are frozen for the lifetime of the predictor
-        try:
+        sig = self._weights_signature()
+        if self._panels.stale() or sig != self._wsig:
+            # the model was trained on (fused optimiser step, or any in-place update that bumped a tensor version) since the
+            # panels were packed: keep the recurrent state, drop everything that holds old weights
+            self._drop_graph_and_panels()
+            self._wsig = sig
+        with self._panels:                            # weights are frozen between optimiser steps: pack each panel once
             if not self.use_graph:
                 return self._eager(x_t)
             if self._graph is None:
@@ -84,8 +98,6 @@ class StreamingPredictor:
             self._static_x.copy_(x_t)
             self._graph.replay()
             return self._static_y.clone()
-        finally:
-            ops.CACHE_PANELS = old_cache
 
     @torch.no_grad()
     def rollout(self, x_seq: torch.Tensor) -> torch.Tensor:
