@@ -1,0 +1,160 @@
+"""GPU tests of host-side semantics around the kernels: panel-cache ownership, optimiser checkpointing, evaluation-mode
+BatchNorm backward, cumulative-average BatchNorm, launches split beyond the 2 GiB descriptor range."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import unet_convlstm_amd as U
+    from unet_convlstm_amd import ops
+from oracle import unet_oracle as O
+
+DEV = "cuda"
+
+
+def test_streaming_predictor_after_fused_optimizer_steps_uses_the_new_weights():
+    """train -> StreamingPredictor -> train more with FusedAdamW (raw-pointer update, tensor versions do not move) -> the
+    SAME predictor and a NEW predictor must both predict with the new weights (the round-1 module-global cache returned
+    the first predictor's panels)."""
+    torch.manual_seed(3)
+    model = U.TemporalUNetDualView(1, 1, base_ch=8, use_skip_lstm=True).to(DEV)
+    opt = U.FusedAdamW(model.parameters(), lr=5e-2, weight_decay=0.0, max_grad_norm=None)
+    data = U.SyntheticSequences(2, 4, 32, 32, seed=9, kind="blobs")
+
+    def full_eval():
+        model.eval()
+        with torch.no_grad():
+            o, _ = model(data.x)
+        return torch.stack(o, 1).cpu()
+
+    sp = U.StreamingPredictor(model, use_graph=True, warmup=1)
+    before = sp.rollout(data.x).cpu()
+    assert rel_l2(before, full_eval()) <= 2e-3
+    model.train()
+    for _ in range(2):
+        U.train_step(model, opt, data.x, data.y, None, False, clip_norm=None)
+    want = full_eval()
+    assert rel_l2(want, before) > 1e-2                        # the weights really moved
+    sp.new_sequence()                                          # SAME predictor object: its graph and panels hold the old weights
+    again = sp.rollout(data.x).cpu()
+    assert rel_l2(again, want) <= 2e-3, "the predictor replayed panels packed from the old weights"
+    fresh = U.StreamingPredictor(model, use_graph=True, warmup=1).rollout(data.x).cpu()
+    assert rel_l2(fresh, want) <= 2e-3
+
+
+def test_fused_adamw_state_dict_roundtrip_resumes_adam():
+    """save -> load into a fresh optimiser -> step must equal stepping the original (moments and bias-correction step kept)."""
+    def make():
+        torch.manual_seed(5)
+        m = U.TemporalUNetDualView(1, 1, base_ch=4, use_skip_lstm=False).to(DEV).train()
+        return m, U.FusedAdamW(m.parameters(), lr=1e-2, weight_decay=1e-4, max_grad_norm=1.0)
+    data = U.SyntheticSequences(2, 3, 32, 32, seed=2, kind="uniform")
+    m1, o1 = make()
+    for _ in range(3):
+        U.train_step(m1, o1, data.x, data.y, None, False)
+    ck_model = {k: v.clone() for k, v in m1.state_dict().items()}
+    ck_opt = o1.state_dict()
+    assert ck_opt["fused"]["step"] == 3 and float(ck_opt["fused"]["exp_avg"].abs().sum()) > 0
+    m2, o2 = make()
+    m2.load_state_dict(ck_model)
+    o2.load_state_dict(ck_opt)
+    o2.flat.flat_g.copy_(o1.flat.flat_g)
+    # identical gradient buffers, identical state: one optimiser step each must give identical parameters
+    o1.step()
+    o2.step()
+    assert o2.step_count == 4
+    assert torch.equal(o1.flat.flat_p, o2.flat.flat_p)
+    m3, o3 = make()
+    m3.load_state_dict(ck_model)
+    o3.flat.flat_g.copy_(o1.flat.flat_g)
+    o3.step()                                                  # a restarted Adam (what dropping the state used to do) differs
+    assert not torch.equal(o1.flat.flat_p, o3.flat.flat_p)
+
+
+def test_eval_mode_batchnorm_backward_matches_oracle():
+    """Backward through frozen BatchNorm statistics (fine-tuning with model.eval()): the reference supports it, round 1
+    raised.  DoubleConv + Down in eval mode, all gradients against the f32 oracle."""
+    torch.manual_seed(17)
+    blk = U.Down(8, 16).to(DEV)
+    with torch.no_grad():
+        for mod in blk.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.5)
+    blk.eval()
+    x = torch.randn(4, 8, 24, 24)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = blk(xd)
+    (yd * yd).sum().backward()
+    sd = {"down." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
+    xr = x.clone().requires_grad_(True)
+    yr = O.down(xr, {**sd, **leaves}, "down", False, None)
+    (yr * yr).sum().backward()
+    assert rel_l2(yd.detach().cpu(), yr.detach()) <= 1e-2
+    print(f"[parity] eval-BN backward: dx {rel_l2(xd.grad.cpu(), xr.grad):.5f}")
+    assert rel_l2(xd.grad.cpu(), xr.grad) <= 3e-2
+    for k, p in blk.named_parameters():
+        e = rel_l2(p.grad.cpu(), leaves["down." + k].grad)
+        print(f"[parity] eval-BN backward: {k} {e:.5f}")
+        assert e <= 3e-2, k
+    for k, v in blk.state_dict().items():                      # eval mode: running statistics untouched
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd["down." + k])
+
+
+def test_batchnorm_momentum_none_is_the_cumulative_average():
+    """BatchNorm2d(momentum=None): running statistics are the cumulative average over calls (factor 1/num_batches_tracked);
+    round 1 silently used 0.1.  Plain PyTorch BatchNorm on the CPU is the reference of this op."""
+    torch.manual_seed(23)
+    dc = U.DoubleConv(3, 8).to(DEV).train()
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8, momentum=None), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.BatchNorm2d(8, momentum=None), torch.nn.ReLU()).train()
+    ref.load_state_dict({k: v.cpu() for k, v in dc.net.state_dict().items()})
+    dc.net[1].momentum = None
+    dc.net[4].momentum = None
+    for i in range(3):
+        x = torch.randn(4, 3, 16, 16)
+        with torch.no_grad():
+            dc(x.to(DEV))
+            ref(x)
+    for k in ("1.running_mean", "1.running_var", "4.running_mean", "4.running_var"):
+        torch.testing.assert_close(dc.net.state_dict()[k].cpu(), ref.state_dict()[k], rtol=2e-2, atol=2e-3)
+    assert int(dc.net[1].num_batches_tracked) == 3
+
+
+def test_launches_beyond_the_descriptor_range_are_split_bit_identically(monkeypatch):
+    """at 256x256 / B=32 / T=8 a batched launch sees 2^31 bytes and the library refused it.  The host layer
+    now cuts such launches into image ranges on BatchNorm-group boundaries.  Forced here with a tiny limit: forward,
+    statistics, input gradients and weight gradients must be bit-identical to the unsplit launches."""
+    def run():
+        torch.manual_seed(29)
+        dc = U.DoubleConv(16, 32).to(DEV).train()
+        x = torch.randn(6, 16, 16, 16)
+        a = ops.ToNHWC.apply(x.to(DEV)).requires_grad_(True)
+        out = dc.forward_nhwc(a, groups=3)
+        (out.float() ** 2).sum().backward()
+        return out.detach().clone(), a.grad.clone(), [p.grad.clone() for p in dc.parameters()], \
+            [b.clone() for b in dc.buffers()]
+    monkeypatch.setattr(ops, "ASYNC_WGRAD", False)
+    whole = run()
+    monkeypatch.setattr(ops, "LAUNCH_BYTES_LIMIT", 2 * 2 * 16 * 16 * 32 * 2 + 1)        # two groups of two images per launch
+    calls = []
+    orig = ops._img_chunks
+    monkeypatch.setattr(ops, "_img_chunks", lambda *a, **k: (calls.append(orig(*a, **k)), calls[-1])[1])
+    split = run()
+    assert any(len(c) > 1 for c in calls), "the limit did not force a split"
+    assert torch.equal(whole[0], split[0]) and torch.equal(whole[1], split[1])
+    for a, b in zip(whole[3], split[3]):
+        assert torch.equal(a, b)
+    for a, b in zip(whole[2], split[2]):
+        # weight gradients: more pixel-range slabs are added in a different order (f32 rounding only)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    monkeypatch.setattr(ops, "LAUNCH_BYTES_LIMIT", 16 * 16 * 32 * 2 - 1)
+    with pytest.raises(U.UclstmError, match="exceeds"):
+        run()

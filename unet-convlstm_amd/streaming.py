@@ -28,6 +28,15 @@ class StreamingPredictor:
         self._shape = None
         self._drop_graph_and_panels()
 
+    def new_sequence(self) -> None:
+        """Zero the recurrent state IN PLACE (the captured graph keeps updating these very buffers): the next frame starts a
+        new sequence of the same shape, the graph and the packed panels stay."""
+        if self._state is not None:
+            for layers in self._state.values():
+                for h, c in layers:
+                    h.zero_()
+                    c.zero_()
+
     def _drop_graph_and_panels(self) -> None:
         # order matters: the captured graph has the panels' addresses baked in, so it goes first; the panels are owned by
         # this predictor's cache (never by a module-global one) and die with it
