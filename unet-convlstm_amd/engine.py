@@ -46,7 +46,10 @@ class SyntheticSequences:
                     vx = int(torch.randint(-5, 6, (1,), generator=g))
                     vy = int(torch.randint(-5, 6, (1,), generator=g))
                     for t in range(T):
-                        blob = torch.exp(-((xx - px) ** 2 + (yy - py) ** 2) / (2.0 * (r / 2.0) ** 2))
+                        # bump 1/(1+q)^2 in f64 from IEEE basic operations only (+, *, /): bit-identical on every host CPU
+                        # (exp() differs by an ulp between vector ISAs, which breaks seed-regenerated fixtures)
+                        q = ((xx - px).double() ** 2 + (yy - py).double() ** 2) / (2.0 * (r / 2.0) ** 2)
+                        blob = (1.0 / ((1.0 + q) * (1.0 + q))).float()
                         on = blob > 0.1
                         x[b, t, :, on] = torch.maximum(x[b, t, :, on], blob[on])
                         y[b, t, 0][on] = vx / 5.0
