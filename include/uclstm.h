@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 6
+#define UCLSTM_ABI_VERSION 7
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -93,6 +93,10 @@ typedef struct {
     float* c_out;                /* f32 [pixels][Hd_p] */
     void* h_out;                 /* bf16 [pixels][Hd_p] */
     void* gates_out;             /* bf16 [pixels][4][Hd_p] post-activation i,f,g,o or NULL (inference) */
+    const float* pre_add;        /* f32 [pixels][N] or NULL: pre-activations added to the GEMM result before the
+                                  * nonlinearities, in panel-row order -- the x half W_x * x_t of the gate convolution when
+                                  * it has been hoisted out of the recurrence (train/unet.py:55-57 recomputes it inside the
+                                  * time loop; it does not depend on h) and this launch carries only W_h * h_{t-1} */
     /* UCLSTM_EPI_ATOMIC: acc_out[pixel*acc_ld + n] += tile (no bias); the caller zeroes / pre-loads acc_out.
      * acc_slab > 0: no atomics -- K range r STORES its tile into acc_out + r*acc_slab (floats); every element of each
      * of the uclstm_igemm_ksplit_used() slabs is written exactly once and the consumer adds the slabs
@@ -237,8 +241,10 @@ int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const 
                                   float* dc_io, int32_t dc_is_zero, void* dgates, int64_t pixels, int32_t Hd_p, void* stream);
 /* Gate nonlinearities + cell update (train/unet.py:29-35) for the split-K form of the cell: `pre` is the f32
  * pre-activation [pixels][N] in the gate-interleaved panel-row order (N = 64*ceil(Hd/16)), bias in the same order. */
-int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab /* pre-activation = sum of nslab slabs */, int64_t slab /* floats between slabs */,
+int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab /* pre-activation = sum of nslab slabs (0 allowed with pre_add) */,
+                                  int64_t slab /* floats between slabs */,
                                   int32_t clear /* != 0: zero what was read (atomic accumulator reused by the next step) */,
+                                  const float* pre_add /* f32 [pixels][N] or NULL: added to the slabs (hoisted W_x * x_t) */,
                                   const float* bias, const float* c_prev, float* c_out, void* h_out,
                                   void* gates_out, int64_t pixels, int32_t Hd_p, void* stream);
 

@@ -4,6 +4,7 @@ data-parallel path is correct with world_size 2 on gloo.  No kernel is launched 
 import ctypes as C
 import inspect
 import os
+import re
 import sys
 
 import numpy as np
@@ -31,7 +32,8 @@ def test_library_exports_every_header_symbol():
     raw = C.CDLL(L.LIB_PATH)
     for s in syms:
         assert hasattr(raw, s), s
-    assert L.lib.uclstm_abi_version() == L.ABI_VERSION == 6
+    hdr = open(L.HEADER_PATH).read()
+    assert L.lib.uclstm_abi_version() == L.ABI_VERSION == int(re.search(r"#define UCLSTM_ABI_VERSION (\d+)", hdr).group(1))
     assert L.lib.uclstm_build_arch() == b"gfx950"
 
 
@@ -42,6 +44,12 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.PackDesc) == 4 * 17 + 4 + 8 * 4      # 17 ints (+4 pad) + 4 int64
     d = L.IgemmDesc()
     assert C.sizeof(d) % 8 == 0 and type(d).src.offset == 32 and type(d).wp.offset == 96
+    # v7: pre_add sits between the LSTM outputs and the split-K block
+    assert type(d).pre_add.offset == type(d).gates_out.offset + 8 and type(d).acc_out.offset == type(d).pre_add.offset + 8
+    h = ops.lstm_half_pack_desc(40, 24, "h")
+    x = ops.lstm_half_pack_desc(40, 24, "x")
+    full = ops.lstm_pack_desc(40, 24)
+    assert h.N == x.N == full.N and h.Ktot + x.Ktot == full.Ktot and (h.choff[0], x.choff[0]) == (24, 0)
 
 
 def test_argument_contracts_are_checked_before_launch():

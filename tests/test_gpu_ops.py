@@ -502,7 +502,7 @@ def test_lstm_fused_kernel_and_split_k_form_agree(B, H, W, Cx, Hd):
     pre = torch.zeros(B * H * W, wp.shape[0], device=DEV)
     ops.igemm_atomic([ops.SrcView(x), ops.SrcView(h)], wp, (H, W), B, pre, 5, ktap=3, pad=1)
     L = U._lib
-    L.check(L.lib.uclstm_lstm_fwd_pointwise(pre.data_ptr(), 1, 0, 1, bp.data_ptr(), c.data_ptr(), c2.data_ptr(), h2.data_ptr(), g2.data_ptr(),
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(pre.data_ptr(), 1, 0, 1, None, bp.data_ptr(), c.data_ptr(), c2.data_ptr(), h2.data_ptr(), g2.data_ptr(),
                                             B * H * W, Hdp, None), "lstm_fwd_pointwise")
     assert float(pre.abs().max()) == 0.0, "clear != 0 must leave a zero accumulator"
     check_f32(c2.cpu(), c1.cpu(), "split-K cell c vs fused", l2=1e-5)
@@ -514,10 +514,38 @@ def test_lstm_fused_kernel_and_split_k_form_agree(B, H, W, Cx, Hd):
     slabs = torch.full((nsl, B * H * W, wp.shape[0]), float("nan"), device=DEV)
     ops.igemm_atomic([ops.SrcView(x), ops.SrcView(h)], wp, (H, W), B, slabs, 5, ktap=3, pad=1, slabs=True)
     assert bool(torch.isfinite(slabs).all()), "every slab element must be written"
-    L.check(L.lib.uclstm_lstm_fwd_pointwise(slabs.data_ptr(), nsl, slabs.stride(0), 0, bp.data_ptr(), c.data_ptr(), c3.data_ptr(),
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(slabs.data_ptr(), nsl, slabs.stride(0), 0, None, bp.data_ptr(), c.data_ptr(), c3.data_ptr(),
                                             h3.data_ptr(), g3.data_ptr(), B * H * W, Hdp, None), "lstm_fwd_pointwise")
     check_f32(c3.cpu(), c1.cpu(), "slab split-K cell c vs fused", l2=1e-5)
     check_bf16(h3.float().cpu(), h1.float().cpu(), "slab split-K cell h vs fused", l2=1e-3, mx=8e-3)
+    # hoisted form: W_x * x as its own GEMM into f32 pre-activations, the step carries W_h * h only --
+    # (a) fused kernel with pre_add, (b) split-K slabs + point-wise kernel with pre_add, (c) zero-h step: point-wise only
+    wx = ops.pack_weights(ops.lstm_half_pack_desc(Hd, Cx, "x"), wt)
+    wh = ops.pack_weights(ops.lstm_half_pack_desc(Hd, Cx, "h"), wt)
+    assert wx.shape[0] == wh.shape[0] == wp.shape[0] and wx.shape[1] + wh.shape[1] == wp.shape[1]
+    pre_x = torch.full((1, B * H * W, wx.shape[0]), float("nan"), device=DEV)
+    ops.igemm_atomic([ops.SrcView(x)], wx, (H, W), B, pre_x, 1, ktap=3, pad=1, slabs=True)
+    assert bool(torch.isfinite(pre_x).all())
+    c4, h4, g4 = outs()
+    ops.igemm_lstm(None, h, wh, bp, c, c4, h4, g4, pre_add=pre_x[0])
+    check_f32(c4.cpu(), c1.cpu(), "hoisted fused cell c vs two-source fused", l2=1e-5)
+    check_bf16(h4.float().cpu(), h1.float().cpu(), "hoisted fused cell h vs two-source fused", l2=1e-3, mx=8e-3)
+    check_bf16(g4.float().cpu(), g1.float().cpu(), "hoisted fused cell gates vs two-source fused", l2=1e-3, mx=8e-3)
+    c5, h5, g5 = outs()
+    nsl_h = ops.ksplit_used(wh.shape[1], 3)
+    slabs_h = torch.full((nsl_h, B * H * W, wh.shape[0]), float("nan"), device=DEV)
+    ops.igemm_atomic([ops.SrcView(h)], wh, (H, W), B, slabs_h, 3, ktap=3, pad=1, slabs=True)
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(slabs_h.data_ptr(), nsl_h, slabs_h.stride(0), 0, pre_x.data_ptr(), bp.data_ptr(), c.data_ptr(),
+                                            c5.data_ptr(), h5.data_ptr(), g5.data_ptr(), B * H * W, Hdp, None), "lstm_fwd_pointwise")
+    check_f32(c5.cpu(), c1.cpu(), "hoisted split-K cell c vs two-source fused", l2=1e-5)
+    check_bf16(h5.float().cpu(), h1.float().cpu(), "hoisted split-K cell h vs two-source fused", l2=1e-3, mx=8e-3)
+    c6, h6, g6 = outs()
+    L.check(L.lib.uclstm_lstm_fwd_pointwise(None, 0, 0, 0, pre_x.data_ptr(), bp.data_ptr(), None, c6.data_ptr(), h6.data_ptr(), g6.data_ptr(),
+                                            B * H * W, Hdp, None), "lstm_fwd_pointwise")
+    c7, h7, g7 = outs()
+    ops.igemm_lstm(x, torch.zeros_like(h), wp, bp, None, c7, h7, g7)
+    check_f32(c6.cpu(), c7.cpu(), "zero-state step (point-wise only) c vs fused with h = 0", l2=1e-5)
+    check_bf16(h6.float().cpu(), h7.float().cpu(), "zero-state step h vs fused with h = 0", l2=1e-3, mx=8e-3)
     # and against the oracle on the same rounded operands
     xr, hr = from_nhwc(x, Cx), from_nhwc(h, Hd)
     cr = c[..., :Hd].cpu().permute(0, 3, 1, 2)

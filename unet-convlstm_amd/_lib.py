@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -52,7 +52,7 @@ class IgemmDesc(C.Structure):
                 ("nseg", C.c_int32), ("seg", Seg * 4),
                 ("stats", C.c_void_p),
                 ("Hd_p", C.c_int32), ("c_prev", C.c_void_p), ("c_out", C.c_void_p), ("h_out", C.c_void_p),
-                ("gates_out", C.c_void_p),
+                ("gates_out", C.c_void_p), ("pre_add", C.c_void_p),
                 ("acc_out", C.c_void_p), ("acc_ld", C.c_int32), ("ksplit", C.c_int32), ("acc_slab", C.c_int64)]
 
 
@@ -98,7 +98,7 @@ _PROTOS = {
     "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "uclstm_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P, _L, _I, _P],
-    "uclstm_lstm_fwd_pointwise": [_P, _I, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P],
+    "uclstm_lstm_fwd_pointwise": [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "uclstm_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],
     "uclstm_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
     "uclstm_nchw_grad_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],

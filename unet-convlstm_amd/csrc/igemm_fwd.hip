@@ -473,12 +473,19 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                     }
                     float cn[4];
                     Pack8 hi, gi, gf, gg, go;
+                    float xa[4][4];                 // hoisted W_x * x_t of this pixel's four gate quads (or zeros)
+#pragma unroll
+                    for (int gate = 0; gate < 4; ++gate) {
+                        const float4 t = d.pre_add ? *(const float4*)(d.pre_add + pix * d.N + n0 + wc * 64 + gate * 16 + lq * 4)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                        xa[gate][0] = t.x; xa[gate][1] = t.y; xa[gate][2] = t.z; xa[gate][3] = t.w;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float vi = fast_sigmoid(acc[0][b][r] + bg[0][r]);
-                        const float vf = fast_sigmoid(acc[1][b][r] + bg[1][r]);
-                        const float vg = fast_tanh(acc[2][b][r] + bg[2][r]);
-                        const float vo = fast_sigmoid(acc[3][b][r] + bg[3][r]);
+                        const float vi = fast_sigmoid(acc[0][b][r] + xa[0][r] + bg[0][r]);
+                        const float vf = fast_sigmoid(acc[1][b][r] + xa[1][r] + bg[1][r]);
+                        const float vg = fast_tanh(acc[2][b][r] + xa[2][r] + bg[2][r]);
+                        const float vo = fast_sigmoid(acc[3][b][r] + xa[3][r] + bg[3][r]);
                         cn[r] = vf * cp[r] + vi * vg;                 // train/unet.py:34
                         hi.e[r] = f32_to_bf16(vo * fast_tanh(cn[r])); // train/unet.py:35
                         gi.e[r] = f32_to_bf16(vi);
@@ -1075,7 +1082,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
         // validated above
     } else if (d.epi == UCLSTM_EPI_LSTM) {
         if (d.Hd_p <= 0 || (d.Hd_p % 8) || (d.N % 64) || d.N != 64 * ((d.Hd_p + 15) / 16)) return UCLSTM_E_BADARG;
-        if (!d.c_out || !d.h_out) return UCLSTM_E_BADARG;
+        if (!d.c_out || !d.h_out || (d.pre_add && ((uintptr_t)d.pre_add % 16))) return UCLSTM_E_BADARG;
     } else if (d.epi == UCLSTM_EPI_STORE) {
         if (d.nseg < 1 || d.nseg > 4) return UCLSTM_E_BADARG;
         for (int i = 0; i < d.nseg; ++i) {

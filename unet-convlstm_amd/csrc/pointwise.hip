@@ -407,7 +407,8 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // ---------------------------------------------------------------------------------------------
 // Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
 // (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
-__global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ bias,
+__global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ pre_add,
+                                   const float* __restrict__ bias,
                                    const float* __restrict__ c_prev, float* __restrict__ c_out, bf16* __restrict__ h_out,
                                    bf16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
@@ -418,13 +419,14 @@ __global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clea
         float g4[4][4];
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
-            float4 v = *(const float4*)(pp + gate * 16);
-            for (int sl = 1; sl < nslab; ++sl) {          // split-K slabs (plain stores of the K ranges)
-                const float4 u = *(const float4*)(pp + sl * slab + gate * 16);
+            // hoisted x half of the gate convolution (one GEMM over all timesteps) + the split-K slabs of W_h * h_{t-1}
+            float4 v = pre_add ? *(const float4*)(pre_add + (int64_t)pix * N + nb + gate * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sl = 0; sl < nslab; ++sl) {          // split-K slabs (plain stores of the K ranges)
+                const float4 u = *(const float4*)(pp + (int64_t)sl * slab + gate * 16);
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
             // consume-and-clear: an atomic split-K GEMM of the next timestep accumulates into this buffer again
-            if (clear) *(float4*)(const_cast<float*>(pp) + gate * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (clear && nslab > 0) *(float4*)(const_cast<float*>(pp) + gate * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 b = bias ? *(const float4*)(bias + nb + gate * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             g4[gate][0] = v.x + b.x; g4[gate][1] = v.y + b.y; g4[gate][2] = v.z + b.z; g4[gate][3] = v.w + b.w;
         }
@@ -920,15 +922,17 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, const void
     return UCLSTM_OK;
 }
 
-extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t slab, int32_t clear, const float* bias, const float* c_prev, float* c_out, void* h_out,
-                                             void* gates_out, int64_t pixels, int32_t Hd_p, void* stream) {
-    if (!aligned16(pre) || !aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
+extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t slab, int32_t clear, const float* pre_add, const float* bias,
+                                             const float* c_prev, float* c_out, void* h_out, void* gates_out, int64_t pixels, int32_t Hd_p,
+                                             void* stream) {
+    if (!aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
+    if (nslab < 0 || (nslab > 0 && (!pre || !aligned16(pre))) || (nslab == 0 && !pre_add) || (pre_add && !aligned16(pre_add))) return UCLSTM_E_BADARG;
     if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return UCLSTM_E_BADARG;
     const int64_t items = pixels * (Hd_p / 4);
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     const int N = 64 * ((Hd_p + 15) / 16);
-    if (nslab < 1 || (nslab > 1 && (slab <= 0 || (slab % 4)))) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, bias, c_prev, c_out, (bf16*)h_out,
+    if (nslab > 1 && (slab <= 0 || (slab % 4))) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, pre_add, bias, c_prev, c_out, (bf16*)h_out,
                   (bf16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
     return UCLSTM_OK;
 }

@@ -163,6 +163,25 @@ def lstm_pack_desc(Hd: int, Cx: int, ksize: int = 3) -> L.PackDesc:
     return d
 
 
+def lstm_half_pack_desc(Hd: int, Cx: int, half: str, ksize: int = 3) -> L.PackDesc:
+    """One half of the gate convolution as its own gate-interleaved panel: ``half='x'`` = W_x (input channels [0, Cx) of
+    train/unet.py:19's conv, applied to x_t), ``'h'`` = W_h (channels [Cx, Cx+Hd), applied to h_{t-1}).  W_x * x_t does not
+    depend on the recurrence, so it is hoisted out of the time loop of train/unet.py:55-57 and computed for all timesteps
+    by one GEMM; the serial step then carries only W_h * h_{t-1} (half the K, half the weight traffic per step)."""
+    taps = ksize * ksize
+    cs = Cx if half == "x" else Hd
+    d = L.PackDesc()
+    d.N, d.taps, d.nsrc = 64 * ((Hd + 15) // 16), taps, 1
+    d.kseg[0], d.kseg[1] = kseg(cpad(cs)), 0
+    d.cvalid[0], d.cvalid[1] = cs, 0
+    d.choff[0], d.choff[1] = (0 if half == "x" else Cx), 0
+    d.Ktot = taps * d.kseg[0]
+    d.n_mode, d.n_valid, d.n_cp = L.NMODE_LSTM, Hd, 0
+    d.k_mode, d.k_hdp, d.k_hd, d.tap_flip = L.KMODE_IDENTITY, 0, 0, 0
+    d.stride_n, d.stride_k, d.stride_tap, d.stride_ntap = (Cx + Hd) * taps, taps, 1, 0
+    return d
+
+
 def lstm_dgrad_pack_desc(Hd: int, Cx: int, c_valid_s: int, ksize: int = 3) -> L.PackDesc:
     """Input-gradient panel of the gate conv for one source (x or h); K = (flipped tap, gate*Hd_p + hc)."""
     taps = ksize * ksize
@@ -378,6 +397,7 @@ def _fold_slabs(dwp: torch.Tensor) -> torch.Tensor:
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+HOIST_X = os.environ.get("UCLSTM_HOIST_X", "1") != "0"               # x half of the ConvLSTM gate conv as one GEMM over all T
 POOL_SKIP = os.environ.get("UCLSTM_POOL_SKIP", "1") != "0"            # skip-connection gradient added inside max-pool backward
 DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
 GRAD_SIDE_HOOKS: list = []
@@ -595,7 +615,7 @@ def ksplit_used(Ktot: int, ksplit: int) -> int:
 
 
 def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
-                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False) -> None:
+                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False, kind: str = "igemm_fwd_atomic") -> None:
     """Split-K convolution as `ksplit` K ranges.  ``slabs=False``: acc_out[pixel, n] += ... with f32 atomics
     (acc_out f32 [pixels, ld>=N], zeroed by the caller).  ``slabs=True``: acc_out is [ksplit_used, pixels, ld]; range r
     stores into acc_out[r] and the consumer adds the slabs (plain stores run ~4.6x faster than float atomics)."""
@@ -613,18 +633,27 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
         raise L.UclstmError("igemm_atomic(slabs=True): acc_out must be a contiguous [ksplit_used, pixels, ld] tensor")
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
     _log_shape(d)
-    _timed("igemm_fwd_atomic", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
+    _timed(kind, flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
 
 
-def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
-               c_out: torch.Tensor, h_out: torch.Tensor, gates_out: Optional[torch.Tensor], ksize: int = 3) -> None:
+def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
+               c_out: torch.Tensor, h_out: torch.Tensor, gates_out: Optional[torch.Tensor], ksize: int = 3,
+               pre_add: Optional[torch.Tensor] = None) -> None:
+    """Fused ConvLSTM cell step.  ``x`` given: gate conv over (x_t, h_{t-1}) with the two-source panel.  ``x=None``: the
+    launch carries W_h * h_{t-1} only and ``pre_add`` (f32 [pixels, N]) holds the hoisted W_x * x_t."""
     d = L.IgemmDesc()
-    B, H, W, _ = x.shape
+    B, H, W, _ = h_prev.shape
     d.n_img, d.H, d.W, d.groups = B, H, W, 1
-    d.ktap, d.scale, d.pad, d.nsrc = ksize, 1, ksize // 2, 2
-    SrcView(x).fill(d.src[0])
-    SrcView(h_prev).fill(d.src[1])
+    d.ktap, d.scale, d.pad = ksize, 1, ksize // 2
+    if x is not None:
+        d.nsrc = 2
+        SrcView(x).fill(d.src[0])
+        SrcView(h_prev).fill(d.src[1])
+    else:
+        d.nsrc = 1
+        SrcView(h_prev).fill(d.src[0])
+    d.pre_add = None if pre_add is None else _dev(pre_add, F32, "pre_add").data_ptr()
     d.wp, d.N, d.Ktot = wp.data_ptr(), wp.shape[0], wp.shape[1]
     d.bias = None if bias is None else bias.data_ptr()
     d.relu, d.epi, d.nseg = 0, L.EPI_LSTM, 0
@@ -632,7 +661,7 @@ def igemm_lstm(x: torch.Tensor, h_prev: torch.Tensor, wp: torch.Tensor, bias: Op
     d.c_prev = None if c_prev is None else c_prev.data_ptr()
     d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
-    flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * (x.shape[3] + h_prev.shape[3])
+    flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * ((x.shape[3] if x is not None else 0) + h_prev.shape[3])
     _log_shape(d)
     _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
            f"M={B * H * W} N={d.N} K={d.Ktot}")
@@ -1083,7 +1112,6 @@ class ConvLSTMSeq(torch.autograd.Function):
         dev = x_all.device
         ks = weight.shape[-1]
         pd = lstm_pack_desc(Hd, Cx, ks)
-        wp = pack_weights(pd, weight)
         bp = pack_bias(pd, bias) if bias is not None else None
         h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=BF16, device=dev)
         c_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=F32, device=dev)
@@ -1094,22 +1122,43 @@ class ConvLSTMSeq(torch.autograd.Function):
         if c0 is not None:
             c_hist[0].copy_(c0)
         gates = torch.empty((T, B, H, W, 4, Hdp), dtype=BF16, device=dev) if need_grad else None
-        # Per-step GEMM M = B*H*W.  When its 128x128 tile grid cannot fill the chip (bottleneck LSTM: M = 512), run the
-        # gate convolution as split-K partial tiles accumulated in f32 and apply the cell update in a point-wise kernel;
-        # otherwise one fused kernel per step (gates never leave registers).
-        ksplit = split_k_factor(B * H * W, wp.shape[0], wp.shape[1] // 64)
+        pixels = B * H * W
+        # Per-step GEMM M = B*H*W.  When its tile grid cannot fill the chip (bottleneck LSTM: M = 512), run the gate
+        # convolution as split-K partial tiles in f32 slabs and apply the cell update in a point-wise kernel; otherwise one
+        # fused kernel per step (gates never leave registers).
+        hoist = HOIST_X and T >= 2
+        if hoist:
+            # W_x * x_t for ALL timesteps as one GEMM over T*B*H*W pixels (f32 pre-activations in panel-row order); the
+            # recurrence then multiplies only by W_h: K and the weight bytes re-read per step halve
+            wx = pack_weights(lstm_half_pack_desc(Hd, Cx, "x", ks), weight)
+            wp = pack_weights(lstm_half_pack_desc(Hd, Cx, "h", ks), weight)
+            N = wp.shape[0]
+            pre_x = torch.empty((1, T * pixels, N), dtype=F32, device=dev)
+            for i0, i1 in _img_chunks(T * B, 1, max(_bytes_per_img(x_all[0]), H * W * N * 4), "convlstm x half"):
+                igemm_atomic([SrcView(x_all.view(T * B, H, W, Cxp)[i0:i1])], wx, (H, W), i1 - i0,
+                             pre_x[:, i0 * H * W:i1 * H * W], 1, ktap=ks, pad=ks // 2, slabs=True, kind="igemm_fwd_xhoist")
+            pre_x = pre_x.view(T, pixels, N)
+        else:
+            wp = pack_weights(pd, weight)
+        ksplit = split_k_factor(pixels, wp.shape[0], wp.shape[1] // 64)
         # one f32 slab per K range (plain stores; the point-wise kernel adds them): no atomics, nothing to zero
         nsl = ksplit_used(wp.shape[1], ksplit) if ksplit > 1 else 0
-        pre = torch.empty((nsl, B * H * W, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
+        pre = torch.empty((nsl, pixels, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
             c_prev = c_hist[t] if (c0 is not None or t > 0) else None
             g_t = gates[t] if need_grad else None
-            if ksplit > 1:
-                igemm_atomic([SrcView(x_all[t]), SrcView(h_hist[t])], wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2, slabs=True)
-                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(bp), _p(c_prev), _p(c_hist[t + 1]),
-                                                        _p(h_hist[t + 1]), _p(g_t), B * H * W, Hdp, _stream()), "lstm_fwd_pointwise")
+            px_t = pre_x[t] if hoist else None
+            srcs = ([] if hoist else [SrcView(x_all[t])]) + [SrcView(h_hist[t])]
+            if hoist and t == 0 and h0 is None:
+                # zero initial state (train/unet.py:23-25): W_h * 0 = 0, the step is the point-wise update of W_x * x_0
+                L.check(L.lib.uclstm_lstm_fwd_pointwise(None, 0, 0, 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[1]), _p(h_hist[1]),
+                                                        _p(g_t), pixels, Hdp, _stream()), "lstm_fwd_pointwise")
+            elif ksplit > 1:
+                igemm_atomic(srcs, wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2, slabs=True)
+                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[t + 1]),
+                                                        _p(h_hist[t + 1]), _p(g_t), pixels, Hdp, _stream()), "lstm_fwd_pointwise")
             else:
-                igemm_lstm(x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks)
+                igemm_lstm(None if hoist else x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks, pre_add=px_t)
         if need_grad:
             ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates)
             ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
