@@ -179,7 +179,8 @@ typedef struct {
  * -> bf16 panel [N][Ktot] (zero padded). */
 int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream);
 /* f32 panel gradient [N][Ktot] -> f32 gradient in the reference layout:
- * grad = (accumulate ? grad : 0) + dWp  on every valid element. */
+ * grad = (accumulate ? grad : 0) + dWp  on every valid element.  With more than 64 slabs the slabs are first folded into
+ * slab 0 in place: dwp is scratch of the weight-gradient GEMM and is CONSUMED by this call. */
 int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab /* dWp = sum of nslab slabs */,
                             int64_t slab /* floats between slabs */, float* grad, int32_t accumulate, void* stream);
 /* bias [n_valid*(4 if LSTM)] f32 -> panel-row order [N] f32 (zero padded). */

@@ -195,7 +195,8 @@ template <int TAPS>
 __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
                                                               bf16* __restrict__ wp) {
     constexpr int RUN = 16 * TAPS;
-    constexpr int PITCH = RUN + 2;                                    // in bf16: 73 dwords per column, odd -> conflict-free reads
+    constexpr int PITCH = RUN + 2;                                    // in bf16: 73 dwords per column, odd -> conflict-free column walks
+    constexpr int NLD = 4 * TAPS;                                     // 64 * RUN / 256 loads per thread
     __shared__ bf16 buf[64 * PITCH];                                  // 18 KiB (already rounded: the panel is bf16), small enough
                                                                       // to share a CU with a 128-KiB weight-gradient block
     __shared__ int64_t kbase[64];
@@ -218,35 +219,67 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
     int nrow = d.n_valid - n0;
     nrow = nrow < 0 ? 0 : (nrow > 16 ? 16 : nrow);
     const int run = nrow * TAPS;
-    // 64*RUN / 256 = 4*TAPS passes; four loads in flight per thread
-    for (int it = 0; it < 4 * TAPS; it += 4) {
-        float v[4];
+    // ALL of the block's loads are issued before the first LDS store (the first version kept four in flight per thread and was
+    // latency-bound at 0.6 TB/s: 4096 blocks x 9 dependent load batches).  Consecutive lanes read consecutive floats of a
+    // column's contiguous (16 rows x taps) run.
+    float v[NLD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (it + u) * 256 + threadIdx.x;
-            const int kl = e / RUN, r = e - kl * RUN;
-            const int64_t kb = kbase[kl];
-            v[u] = (r < run && kb >= 0) ? w[kb + (int64_t)n0 * TAPS + r] : 0.f;
-        }
+    for (int u = 0; u < NLD; ++u) {
+        const int e = u * 256 + threadIdx.x;
+        const int kl = e / RUN, r = e - kl * RUN;
+        const int64_t kb = kbase[kl];
+        v[u] = (r < run && kb >= 0) ? w[kb + (int64_t)n0 * TAPS + r] : 0.f;
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (it + u) * 256 + threadIdx.x;
-            const int kl = e / RUN, r = e - kl * RUN;
-            buf[kl * PITCH + r] = f32_to_bf16(v[u]);
-        }
+    for (int u = 0; u < NLD; ++u) {
+        const int e = u * 256 + threadIdx.x;
+        const int kl = e / RUN, r = e - kl * RUN;
+        buf[kl * PITCH + r] = f32_to_bf16(v[u]);
     }
     __syncthreads();
-    const int kl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool kok = kbase[kl] >= 0;
-    if (kc0 + kl < per_tap) {
-        for (int sgm = wv; sgm < RUN; sgm += 4) {
-            const int nl = sgm / TAPS, t = sgm - nl * TAPS;
-            if (n0 + nl >= d.N) break;
-            const int ts = d.tap_flip ? TAPS - 1 - t : t;
-            const bf16 v = (kok && nl < nrow) ? buf[kl * PITCH + nl * TAPS + ts] : f32_to_bf16(0.f);
-            wp[(int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + kl] = v;
+    // output: panel row (n0 + nl), tap t, 64 consecutive K columns = 128 contiguous bytes; a lane gathers 8 columns from LDS
+    // and stores 16 bytes (the first version stored 2 bytes per lane: 36 store instructions per thread instead of 4.5)
+    const int g8 = threadIdx.x & 7;
+    const bool full = kc0 + 64 <= per_tap;
+    for (int sgm = threadIdx.x >> 3; sgm < RUN; sgm += 32) {
+        const int nl = sgm / TAPS, t = sgm - nl * TAPS;
+        if (n0 + nl >= d.N) continue;
+        const int ts = d.tap_flip ? TAPS - 1 - t : t;
+        Pack16 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = nl < nrow ? buf[(g8 * 8 + j) * PITCH + nl * TAPS + ts] : f32_to_bf16(0.f);
+        bf16* dst = wp + (int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + g8 * 8;
+        if (full) {
+            *(uint4*)dst = o.u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kc0 + g8 * 8 + j < per_tap) dst[j] = o.e[j];
         }
     }
+}
+
+// Many-slab panels (C_out <= 64 layers: 64 x 576 elements x ~170 pixel-range slabs): slab 0 += slabs 1..nslab-1 in slab order
+// (deterministic), one float4 column per thread with eight independent loads in flight; the unpack then reads one slab.
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ dwp, int nslab, int64_t slab, int64_t quads) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= quads) return;
+    float4* base = (float4*)dwp + q;
+    const int64_t sq = slab / 4;
+    float4 acc = base[0];
+    int sl = 1;
+    for (; sl + 8 <= nslab; sl += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = base[(sl + j) * sq];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
+    }
+    for (; sl < nslab; ++sl) {
+        const float4 t = base[sl * sq];
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    base[0] = acc;
 }
 
 __global__ void pack_bias_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ b, float* __restrict__ bp) {
@@ -316,6 +349,14 @@ extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w
 extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab, int64_t slab, float* grad,
                                        int32_t accumulate, void* stream) {
     if (!desc_ok(d) || !dwp || !grad || nslab < 1 || (nslab > 1 && slab < (int64_t)d->N * d->Ktot)) return UCLSTM_E_BADARG;
+    if (rows_family(*d) && nslab > 64 && (slab % 4) == 0 && ((int64_t)d->N * d->Ktot % 4) == 0 && ((uintptr_t)dwp % 16) == 0) {
+        // hundreds of small slabs: fold them into slab 0 first (the slabs are scratch of the weight-gradient GEMM and are
+        // CONSUMED here), then unpack a single slab
+        const int64_t quads = (int64_t)d->N * d->Ktot / 4;
+        UCLSTM_LAUNCH(slab_fold_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(dwp), nslab, slab,
+                      quads);
+        nslab = 1;
+    }
     if (rows_family(*d) && nslab <= 64) {
         const int ch0 = (d->kseg[0] + 255) / 256, ch1 = (d->kseg[1] + 255) / 256;
         const dim3 grid(ch0 + ch1, d->N);

@@ -368,7 +368,6 @@ def pack_bias(desc: L.PackDesc, b: torch.Tensor) -> torch.Tensor:
 def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
     """dwp: f32 panel gradient [N, Ktot] or its per-pixel-range slabs [splits, N, Ktot] (added up here)."""
     grad = torch.empty_like(like, dtype=F32, memory_format=torch.contiguous_format)
-    dwp = _fold_slabs(dwp)
     ns, st = _slabs_of(dwp)
     L.check(L.lib.uclstm_unpack_wgrad(C.byref(desc), _p(dwp), ns, st, _p(grad), 0, _stream()), "unpack_wgrad")
     return grad
@@ -376,14 +375,6 @@ def unpack_wgrad(desc: L.PackDesc, dwp: torch.Tensor, like: torch.Tensor) -> tor
 
 def _slabs_of(dwp: torch.Tensor) -> Tuple[int, int]:
     return (dwp.shape[0], dwp.stride(0)) if dwp.dim() == 3 else (1, 0)
-
-
-def _fold_slabs(dwp: torch.Tensor) -> torch.Tensor:
-    """Small panels whose weight gradient used hundreds of pixel ranges (C_out <= 64 layers: 64 x 576 elements x 170
-    slabs): one reduction over the slab axis first, so that the unpack kernel reads a single slab."""
-    if dwp.dim() == 3 and dwp.shape[0] > 64:
-        return dwp.sum(dim=0, keepdim=True)
-    return dwp
 
 
 # ---------------------------------------------------------------------------------------------
@@ -487,7 +478,7 @@ def wgrad_into_param(weight: torch.Tensor, desc: L.PackDesc, inputs: Sequence[to
     with torch.cuda.stream(side):
         _WGRAD_OVERLAPPED = True
         try:
-            dwp = _fold_slabs(run_gemm())
+            dwp = run_gemm()
         finally:
             _WGRAD_OVERLAPPED = False
         ns, st = _slabs_of(dwp)
