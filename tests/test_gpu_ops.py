@@ -169,7 +169,8 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
     reads, 128 x 256 tiles) walks K in the same order as the per-tap loop, so every output must be bit-identical and the
     BatchNorm partial sums equal up to their f32 summation order.  Covers: one image per tile (16x16), four images per tile
     (8x8), sixteen (4x4), image rows (32x32, 64x64), tiles that start mid-row and cross an image boundary (16x24), a second source, a
-    partial last panel tile (N = 192), split-K slabs, the fused ConvLSTM epilogue.  The per-tap loop runs in a subprocess
+    partial last panel tile (N = 192), split-K slabs, the fused ConvLSTM epilogue, and images 128 / 192 / 256 pixels wide
+    (strip tiles: 4 rows x 64 columns with real halo columns).  The per-tap loop runs in a subprocess
     with UCLSTM_FWD_PATCH=0 (the switch is read once per process)."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -182,7 +183,9 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         ops.SHAPE_LOG = []
         #        imgs H   W   C0   C1   Co  groups
         cases = [(8, 16, 16, 128, 0, 128, 2), (16, 8, 8, 128, 64, 256, 4), (4, 32, 32, 128, 0, 192, 1), (2, 64, 64, 128, 0, 128, 1),
-                 (8, 16, 24, 64, 64, 128, 1), (64, 4, 4, 128, 64, 256, 2)]
+                 (8, 16, 24, 64, 64, 128, 1), (64, 4, 4, 128, 64, 256, 2),
+                 # images wider than 64 pixels: 4-row x 64-column STRIP tiles (halo columns = real pixels of the neighbouring strip)
+                 (2, 8, 128, 128, 0, 128, 2), (1, 12, 256, 64, 64, 192, 1), (3, 4, 192, 128, 0, 128, 3)]
         for ci, (N, H, W, C0, C1, Co, groups) in enumerate(cases):
             xs = [(torch.randn(N, H, W, C0) * 0.7).to(torch.bfloat16).cuda()]
             if C1:
@@ -224,6 +227,15 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         gates = torch.empty(B, H, W, 4 * Hd, dtype=torch.bfloat16, device="cuda")
         ops.igemm_lstm(x, h, wp, bp, c, c_out, h_out, gates)
         res["lstm_c"], res["lstm_h"], res["lstm_g"] = c_out.cpu(), h_out.cpu(), gates.cpu()
+        # the same cell on a 128-wide map (strip tiles through the fused epilogue: the 512x512 rollout's skip2 level)
+        B, H, W = 1, 8, 128
+        x = (torch.randn(B, H, W, Cx) * 0.5).to(torch.bfloat16).cuda()
+        h = (torch.randn(B, H, W, Hd) * 0.5).to(torch.bfloat16).cuda()
+        c = torch.randn(B, H, W, Hd).cuda()
+        c_out, h_out = torch.empty_like(c), torch.empty_like(h)
+        gates = torch.empty(B, H, W, 4 * Hd, dtype=torch.bfloat16, device="cuda")
+        ops.igemm_lstm(x, h, wp, bp, c, c_out, h_out, gates)
+        res["lstmw_c"], res["lstmw_h"], res["lstmw_g"] = c_out.cpu(), h_out.cpu(), gates.cpu()
         res["shapes"] = torch.tensor(ops.SHAPE_LOG)
         torch.save(res, sys.argv[1])
     """ % ROOT_DIR)
@@ -234,7 +246,7 @@ def test_patch_loop_is_bit_identical_to_the_per_tap_loop(tmp_path):
         assert r.returncode == 0, r.stderr[-2500:]
         res[tag] = torch.load(f)
     # the library reports which kernel each launch took: every launch of the first run the patch loop, none of the second
-    assert res["patch"]["shapes"].numel() >= 15 and bool((res["patch"].pop("shapes") == 2).all())
+    assert res["patch"]["shapes"].numel() >= 22 and bool((res["patch"].pop("shapes") == 2).all())
     assert bool((res["pertap"].pop("shapes") == 0).all())
     for k, v in res["patch"].items():
         ref = res["pertap"][k]

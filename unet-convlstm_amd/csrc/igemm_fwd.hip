@@ -47,6 +47,10 @@ struct Derived {
     uint32_t xbias[2];   // bytes the source descriptor starts before the tensor (tap (0,0) of a border pixel is "negative")
     uint32_t xbytes[2];  // descriptor size: tensor bytes + bias
     uint32_t wbytes;     // panel bytes
+    // patch shape on images wider than 64 pixels: a tile is a STRIP block of 4 image rows x 64 columns (below)
+    int strip;           // 0: tile = 256 consecutive pixels of the flattened (image, y, x) order; 1: 4 rows x 64 columns
+    int strips;          // W / 64
+    int tiles_per_img;   // (H / 4) * (W / 64)
 };
 
 // Block shapes (SHP): 0 = 128 rows x 128 pixels, waves 2x2;  1 = 64 x 256, waves 1x4 (C_out <= 64);
@@ -114,9 +118,21 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
     const int tile = mt - g * dv.tpg;
     const int m_local0 = tile * TBM;
     const long m0 = (long)g * dv.Mg + m_local0;
-    const int rows_valid = min(TBM, dv.Mg - m_local0);
     const int n0 = nt * TBN;
     const int HW = d.H * d.W;
+    // strip tiles (patch shape, images wider than 64): tile mt = (image, 4-row band, 64-column strip); tile-local pixel r is
+    // image row y0 + (r >> 6), column x0 + (r & 63).  Everything below that needs a pixel's linear index goes through PIX().
+    const bool strip = SHP == 2 && dv.strip;
+    int s_img = 0, s_y0 = 0, s_x0 = 0;
+    if (strip) {
+        s_img = mt / dv.tiles_per_img;
+        const int rem = mt - s_img * dv.tiles_per_img;
+        const int band = rem / dv.strips;
+        s_y0 = band * 4;
+        s_x0 = (rem - band * dv.strips) * 64;
+    }
+    const int rows_valid = strip ? TBM : min(TBM, dv.Mg - m_local0);
+#define PIX(r_) (strip ? ((long)(s_img * d.H + s_y0 + ((r_) >> 6)) * d.W + s_x0 + ((r_) & 63)) : (m0 + (r_)))
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -140,8 +156,12 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         //   128 x 128-B weight tiles (two K-steps in flight, counted vmcnt, one raw s_barrier per K-step).
         constexpr int PROUNDS = SH::PROUNDS, PBYTES = SH::PBYTES, WSLOT = SH::WBYTES;
         unsigned char* const Wring = smem + 2 * PBYTES;
-        const int W1 = d.W + 1;
-        const int PHW = (d.H + 1) * W1;
+        // Images wider than 64 pixels: 256 consecutive pixels would span (2..4 + 2) full image rows of W + 1 patch rows each
+        // -- more than the 448 rows the two patch buffers hold.  There the tile is a 4-row x 64-column block of ONE image and
+        // the patch its (4 + 2) x (64 + 2) neighbourhood = 396 rows of pitch 66: halo rows / columns are real pixels of the
+        // neighbouring band / strip, or zeros (out-of-range DMA) at the image border.  Same K order, same arithmetic.
+        const int W1 = strip ? 66 : d.W + 1;
+        const int PHW = (d.H + 1) * (d.W + 1);
         const int lrow0 = tid >> 3;                        // row within a 64-row DMA round
         const int lchunk = (tid & 7) ^ (lrow0 & 7);        // linear destination, swizzled source (as the per-tap loop)
         const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].ptr, 0, dv.xbytes[0], 0x00020000);
@@ -150,8 +170,8 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, dv.wbytes, 0x00020000);
 
         // patch row 0 = tap (0,0) of the tile's first pixel = q(first) - (W+1) - 1 (negative only for the first tile)
-        int q0;
-        {
+        int q0 = 0;
+        if (!strip) {
             const uint32_t m = (uint32_t)m0;
             const int img = (int)fdiv(m, dv.dHW);
             const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
@@ -163,25 +183,38 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         uint32_t pout = 0;
 #pragma unroll
         for (int i = 0; i < PROUNDS; ++i) {
-            const int q = q0 + lrow0 + SH::RS * i;
-            const uint32_t qu = (uint32_t)max(q, 0);
-            const int img = (int)fdiv(qu, dv.dPHW);
-            const uint32_t rem = qu - (uint32_t)img * (uint32_t)PHW;
-            const int yy = (int)fdiv(rem, dv.dW2);
-            const int xx = (int)rem - yy * W1;
-            const bool in = q >= 0 && yy < d.H && xx < d.W && img < d.n_img;
-            ppix[i] = (uint32_t)((img * d.H + yy) * d.W + xx);
-            pout |= in ? 0u : (1u << i);
+            if (strip) {
+                const int j = lrow0 + SH::RS * i;              // patch row = (band row pr, column pc) of the 6 x 66 neighbourhood
+                const int pr = (j * 993) >> 16;                // j / 66 for j < 448
+                const int yy = s_y0 - 1 + pr, xx = s_x0 - 1 + (j - pr * 66);
+                const bool in = pr < 6 && (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W;
+                ppix[i] = (uint32_t)((s_img * d.H + yy) * d.W + xx);
+                pout |= in ? 0u : (1u << i);
+            } else {
+                const int q = q0 + lrow0 + SH::RS * i;
+                const uint32_t qu = (uint32_t)max(q, 0);
+                const int img = (int)fdiv(qu, dv.dPHW);
+                const uint32_t rem = qu - (uint32_t)img * (uint32_t)PHW;
+                const int yy = (int)fdiv(rem, dv.dW2);
+                const int xx = (int)rem - yy * W1;
+                const bool in = q >= 0 && yy < d.H && xx < d.W && img < d.n_img;
+                ppix[i] = (uint32_t)((img * d.H + yy) * d.W + xx);
+                pout |= in ? 0u : (1u << i);
+            }
         }
         // patch rows this lane READS: the CENTRE tap of pixel wpx*64 + b*16 + l15
         int prow[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const uint32_t m = (uint32_t)(m0 + min(wpx * 64 + b * 16 + l15, rows_valid - 1));
-            const int img = (int)fdiv(m, dv.dHW);
-            const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
-            const int y = (int)fdiv(rem, dv.dW);
-            prow[b] = img * PHW + y * W1 + ((int)rem - y * d.W) - q0;
+            if (strip) {
+                prow[b] = (wpx + 1) * 66 + b * 16 + l15 + 1;   // tile-local pixel (row wpx, column b*16 + l15)
+            } else {
+                const uint32_t m = (uint32_t)(m0 + min(wpx * 64 + b * 16 + l15, rows_valid - 1));
+                const int img = (int)fdiv(m, dv.dHW);
+                const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+                const int y = (int)fdiv(rem, dv.dW);
+                prow[b] = img * PHW + y * W1 + ((int)rem - y * d.W) - q0;
+            }
         }
         uint32_t wvoff[SH::WR];
 #pragma unroll
@@ -465,7 +498,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             for (int b = 0; b < 4; ++b) {
                 const int prow = wpx * 64 + b * 16 + l15;
                 if (prow < rows_valid) {
-                    const long pix = m0 + prow;
+                    const long pix = PIX(prow);
                     float cp[4] = {0.f, 0.f, 0.f, 0.f};
                     if (d.c_prev) {
                         const float4 t = *(const float4*)(d.c_prev + pix * d.Hd_p + hc);
@@ -529,7 +562,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                 for (int pr = tid / TBN; pr < 64; pr += RPI) {
                     const int prow = blk * 64 + pr;
                     if (prow < rows_valid) {
-                        float* dst = d.acc_out + (long)ks * d.acc_slab + (m0 + prow) * (long)d.acc_ld + n;
+                        float* dst = d.acc_out + (long)ks * d.acc_slab + PIX(prow) * (long)d.acc_ld + n;
                         if (d.acc_slab > 0) *dst = At[pr * AP + col];          // this K range's own slab: plain 256-byte runs
                         else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -618,11 +651,18 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             const int cc = q - r * CPR;
             const int n = n0 + cc * 8;
             if (r >= rows_valid || n >= d.N) continue;
-            const uint32_t m = (uint32_t)(m0 + r);
-            const int img = (int)fdiv(m, dv.dHW);
-            const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
-            const int y = (int)fdiv(rem, dv.dW);
-            const int x = (int)rem - y * d.W;
+            int img, y, x;
+            if (strip) {
+                img = s_img;
+                y = s_y0 + (r >> 6);
+                x = s_x0 + (r & 63);
+            } else {
+                const uint32_t m = (uint32_t)(m0 + r);
+                img = (int)fdiv(m, dv.dHW);
+                const uint32_t rem = m - (uint32_t)img * (uint32_t)HW;
+                y = (int)fdiv(rem, dv.dW);
+                x = (int)rem - y * d.W;
+            }
 #pragma unroll
             for (int si = 0; si < 4; ++si) {
                 if (si < d.nseg && n >= d.seg[si].n_begin && n < d.seg[si].n_end) {
@@ -637,6 +677,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             }
         }
     }
+#undef PIX
 #endif
 }
 
@@ -977,17 +1018,21 @@ inline int patch_rows_max(int H, int W, int64_t mg) {
     return (int)(255 + (R - I) + (W + 2) * I + 2 * (W + 2) + 1);
 }
 
-// The launch conditions of the patch shape (SHP 2); everything else takes the per-tap loop.
-inline bool patch_ok(const uclstm_igemm_desc& d, int64_t mg) {
+// The launch conditions of the patch shape (SHP 2); everything else takes the per-tap loop.  Returns 0 (no), 1 (tiles of 256
+// consecutive pixels: images up to 64 wide) or 2 (4-row x 64-column strip tiles: wider images with 64 | W and 4 | H).
+inline int patch_ok(const uclstm_igemm_desc& d, int64_t mg) {
     static const bool off = [] { const char* e = getenv("UCLSTM_FWD_PATCH"); return e && e[0] == '0'; }();
-    if (off || d.ktap != 3 || d.pad != 1 || d.scale != 1 || d.N <= 64 || (mg % 256)) return false;
-    if (d.Ktot < 2 * 9 * BK) return false;       // one chunk: nothing to amortise the patch over (K = 576 measured 11 % slower)
+    static const bool strip_off = [] { const char* e = getenv("UCLSTM_FWD_STRIP"); return e && e[0] == '0'; }();
+    if (off || d.ktap != 3 || d.pad != 1 || d.scale != 1 || d.N <= 64 || (mg % 256)) return 0;
+    if (d.Ktot < 2 * 9 * BK) return 0;       // one chunk: nothing to amortise the patch over (K = 576 measured 11 % slower)
     for (int s = 0; s < d.nsrc; ++s) {
         const uclstm_src& S = d.src[s];
-        if ((S.C % 64) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return false;
+        if ((S.C % 64) || S.Hs != d.H || S.Ws != d.W || S.offY || S.offX) return 0;
     }
-    if ((int64_t)d.n_img * (d.H + 1) * (d.W + 1) >= ((int64_t)1 << 30)) return false;
-    return patch_rows_max(d.H, d.W, mg) <= Shape<2>::PROWS;
+    if ((int64_t)d.n_img * (d.H + 1) * (d.W + 1) >= ((int64_t)1 << 30)) return 0;
+    if (patch_rows_max(d.H, d.W, mg) <= Shape<2>::PROWS) return 1;
+    if (!strip_off && (d.W % 64) == 0 && (d.H % 4) == 0) return 2;
+    return 0;
 }
 
 template <int EPI, int SHP, int NSRC>
@@ -1053,13 +1098,16 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     dv.dW = make_fastdiv((uint32_t)d.W);
     shp = pick_shape(d.N, mg, d.groups, d.epi);
     mg_out = mg;
-    bool patch = patch_ok(d, mg);
+    int patch = patch_ok(d, mg);
     if (patch && d.epi == UCLSTM_EPI_ATOMIC) {            // K ranges must be whole 64-channel chunks (9 taps each)
         if (d.ksplit < 1) return UCLSTM_E_BADARG;
         const int kper = (d.Ktot / BK + d.ksplit - 1) / d.ksplit;
-        patch = (kper % 9) == 0;
+        if ((kper % 9) != 0) patch = 0;
     }
     if (patch) shp = 2;
+    dv.strip = patch == 2;
+    dv.strips = d.W / 64;
+    dv.tiles_per_img = (d.H / 4) * (d.W / 64);
     dv.dPHW = make_fastdiv((uint32_t)((d.H + 1) * (d.W + 1)));
     dv.dW2 = make_fastdiv((uint32_t)(d.W + 1));
     const int bm = shape_pixels(shp), bn = shape_rows(shp);

@@ -388,7 +388,7 @@ def _slabs_of(dwp: torch.Tensor) -> Tuple[int, int]:
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
-HOIST_X = os.environ.get("UCLSTM_HOIST_X", "1") != "0"               # x half of the ConvLSTM gate conv as one GEMM over all T
+HOIST_X = os.environ.get("UCLSTM_HOIST_X", "0") == "1"               # x half of the ConvLSTM gate conv as one GEMM over all T (off: measured slower)
 POOL_SKIP = os.environ.get("UCLSTM_POOL_SKIP", "1") != "0"            # skip-connection gradient added inside max-pool backward
 DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
 GRAD_SIDE_HOOKS: list = []
