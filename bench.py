@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--base-ch", type=int, default=64)
     ap.add_argument("--no-skip-lstm", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"],
+                    help="16-bit storage / MFMA operand type: bf16 (default) or f16 = the fp16 twin kernels with dynamic loss scaling "
+                         "(BASELINE.json configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in FlatDDP even for one rank (exercises the RCCL path)")
@@ -160,7 +163,7 @@ def rollout_bench(a, U, dev, skip):
     fwd_gf = {64: 13.264, 128: 53.06, 256: 212.22, 512: 848.89}.get(a.size) if (a.base_ch, skip) == (64, True) else None
     out = {"metric": f"inference frames/sec, {a.size}x{a.size} stateful rollout", "value": round(a.batch * n / dt, 2), "unit": "frames/s",
            "n_gpus": 1, "steps": n, "warmup": max(a.warmup, 3), "ms_per_step": round(dt / n * 1e3, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) eval, frame-by-frame, "
                                   f"batch {a.batch}, hipGraph={'off' if a.no_graph else 'on'}"},
            "finite": bool(torch.isfinite(y).all())}
@@ -198,12 +201,14 @@ def main():
 
     skip = not a.no_skip_lstm
     torch.manual_seed(1234)
+    if a.dtype == "f16":
+        U.set_compute_dtype(torch.float16)
     if a.sync_wgrad:
         ops.ASYNC_WGRAD = False
     if a.mode == "rollout":
         return rollout_bench(a, U, dev, skip)
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
-    opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0, loss_scale=2.0 ** 14 if a.dtype == "f16" else None)
     ddp = U.FlatDDP(model, opt.flat, grad_dtype=torch.bfloat16 if a.bf16_buckets else None) if (world > 1 or a.force_ddp) else None
     data = U.SyntheticSequences(a.batch, a.seq, a.size, a.size, seed=1 + rank, kind="uniform", device=dev)
     x, y = data.x, data.y
@@ -297,7 +302,7 @@ def main():
                        else f"training frames/sec, {a.size}x{a.size} seq-{a.seq}"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) train step, "
                                    f"{a.size}x{a.size} seq-{a.seq}, per-GPU batch {a.batch}, AdamW+clip",
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},

@@ -298,6 +298,18 @@ int32_t uclstm_sumsq(const float* g, int64_t n, double* out /* accumulates, call
 int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* fp16 training (the _f16 twins below): the backward pass runs on loss * scale so that fp16 activation gradients stay out of
+ * the subnormal range, and g holds scale x the true gradient.  scale_state = DEVICE f32[3] {scale, growth tracker, successful
+ * steps}.  uclstm_adamw_step_scaled is uclstm_adamw_step on g / scale (clip on the unscaled norm when max_norm > 0, Adam's
+ * bias correction from the device-side count of successful steps) and does NOTHING when *sumsq (of the scaled gradients;
+ * required) is not finite; uclstm_loss_scale_update then halves the scale (x backoff) after such a step, or counts a good
+ * step and multiplies the scale by `growth` every `interval` good steps in a row.  No host synchronisation. */
+int32_t uclstm_adamw_step_scaled(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, const float* scale_state,
+                                 void* stream);
+int32_t uclstm_loss_scale_update(float* scale_state, const double* sumsq, float growth, float backoff, int32_t interval,
+                                 void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Data path around the step                              */
 /* ------------------------------------------------------------------------------------ */
@@ -317,6 +329,35 @@ int32_t uclstm_metric_sums(const float* y_pred, const float* y, const float* mas
  * runtime multiplexes onto the same hardware queue serialise; which streams collide changes when e.g. an RCCL
  * communicator has created streams of its own first). */
 int32_t uclstm_stream_spin(int32_t microseconds, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* fp16 twins (BASELINE.json configs[3]: "fp16 MFMA")                                    */
+/* ------------------------------------------------------------------------------------ */
+/* Every entry point above that reads or writes 16-bit activations or weight panels exists a second time with the suffix
+ * _f16 and the IDENTICAL signature, where every "bf16" in the comments above reads "IEEE binary16": activations, h, gates,
+ * gate gradients and panels are _Float16 and the GEMMs issue v_mfma_f32_16x16x32_f16.  Accumulators, cell state, BatchNorm
+ * statistics, weight gradients and everything the optimiser touches are f32 in both families, so the remaining entry
+ * points (finalize / parameter-gradient / unpack / loss / optimiser ...) are shared.  fp16 gradients need loss scaling
+ * (uclstm_loss_scale_update below).  The same sources are compiled twice (csrc/common.h); this is a storage-type twin, not
+ * a second backend. */
+#define UCLSTM_F16_TWIN(fn) __typeof__(fn) fn##_f16;
+UCLSTM_F16_TWIN(uclstm_igemm_fwd)
+UCLSTM_F16_TWIN(uclstm_igemm_wgrad)
+UCLSTM_F16_TWIN(uclstm_pack_weights)
+UCLSTM_F16_TWIN(uclstm_bn_apply_relu)
+UCLSTM_F16_TWIN(uclstm_bn_bwd_reduce)
+UCLSTM_F16_TWIN(uclstm_bn_bwd_apply)
+UCLSTM_F16_TWIN(uclstm_maxpool2_fwd)
+UCLSTM_F16_TWIN(uclstm_maxpool2_bwd)
+UCLSTM_F16_TWIN(uclstm_lstm_bwd_pointwise)
+UCLSTM_F16_TWIN(uclstm_lstm_fwd_pointwise)
+UCLSTM_F16_TWIN(uclstm_nchw_to_nhwc)
+UCLSTM_F16_TWIN(uclstm_nhwc_to_nchw)
+UCLSTM_F16_TWIN(uclstm_nchw_grad_to_nhwc)
+UCLSTM_F16_TWIN(uclstm_im2col3x3_first)
+UCLSTM_F16_TWIN(uclstm_outconv_fwd)
+UCLSTM_F16_TWIN(uclstm_outconv_bwd)
+UCLSTM_F16_TWIN(uclstm_colsum)
 
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);

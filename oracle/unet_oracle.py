@@ -42,7 +42,7 @@ BN_MOMENTUM = 0.1    # idem
 class _RoundSTE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
-        return t.to(torch.bfloat16).to(torch.float32)
+        return t.to(_STORAGE_DTYPE).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -50,17 +50,32 @@ class _RoundSTE(torch.autograd.Function):
 
 
 _EMULATE = False
+_STORAGE_DTYPE = torch.bfloat16
 
 
-class bf16_storage:
+class storage:
+    """Round to ``dtype`` (torch.bfloat16 / torch.float16) wherever the HIP path of that compute dtype stores."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
     def __enter__(self):
-        global _EMULATE
-        self._old = _EMULATE
-        _EMULATE = True
+        global _EMULATE, _STORAGE_DTYPE
+        self._old = (_EMULATE, _STORAGE_DTYPE)
+        _EMULATE, _STORAGE_DTYPE = True, self.dtype
 
     def __exit__(self, *exc):
-        global _EMULATE
-        _EMULATE = self._old
+        global _EMULATE, _STORAGE_DTYPE
+        _EMULATE, _STORAGE_DTYPE = self._old
+
+
+def bf16_storage():
+    return storage(torch.bfloat16)
+
+
+def fp16_storage():
+    """The fp16-MFMA twin kernels (BASELINE.json configs[3]) store IEEE binary16."""
+    return storage(torch.float16)
 
 
 def _q(t: Tensor) -> Tensor:

@@ -267,7 +267,8 @@ def flat_grad(model):
     return torch.cat([p.grad.detach().flatten().double() for _, p in model.named_parameters()])
 
 
-def gen_seeded(tag, *, base_ch, skip, B, T, HW, kind, seed, use_mask, lstm_layers=1, with_step=True, with_autocast=True):
+def gen_seeded(tag, *, base_ch, skip, B, T, HW, kind, seed, use_mask, lstm_layers=1, with_step=True, with_autocast=True,
+               with_fp16=False):
     torch.manual_seed(seed)
     model = TemporalUNetDualView(1, 1, base_ch=base_ch, lstm_layers=lstm_layers, use_skip_lstm=skip, use_attention=False)
     x, y, mask = seeded_inputs(kind, B, T, HW, HW, seed + 1)
@@ -292,6 +293,26 @@ def gen_seeded(tag, *, base_ch, skip, B, T, HW, kind, seed, use_mask, lstm_layer
         arr["grad_norm"] = np.float64(np.sqrt((gnorms ** 2).sum()))
         g32 = flat_grad(model)
         per32 = [p.grad.detach().clone().double() for _, p in model.named_parameters()]
+        for pre, adt in ((("ac16_", torch.float16),) if with_fp16 else ()):
+            # the REFERENCE itself under fp16 autocast with a static loss scale of 2^14 (what any fp16 training does; without it
+            # the 1/N loss gradient underflows binary16): the drift anchor for the fp16-MFMA twin kernels (configs[3])
+            model.load_state_dict(sd0)
+            model.train()
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cpu", dtype=adt):
+                output, _ = model(x)
+            y_ac = torch.stack([o.float() for o in output], dim=1)
+            loss_ac = ref_main.compute_loss(y_ac, y, mask, use_mask)
+            (loss_ac * 16384.0).backward()
+            gac = flat_grad(model) / 16384.0
+            arr[pre + "loss"] = npy(loss_ac)
+            arr[pre + "grad_norm"] = np.float64(float(gac.norm()))
+            arr[pre + "grad_rel_l2"] = np.float64(float((gac - g32).norm() / g32.norm()))
+            arr[pre + "grad_cosine"] = np.float64(float(torch.dot(gac, g32) / (gac.norm() * g32.norm())))
+            err_t = [float((y_ac[:, t] - y_pred[:, t]).detach().double().norm() / y_pred[:, t].detach().double().norm()) for t in range(T)]
+            arr[pre + "out_rel_l2_per_t"] = np.array(err_t, dtype=np.float64)
+            print(f"{tag}: reference fp16-autocast drift: out per-t {[round(e, 5) for e in err_t]}, loss {float(loss_ac):.6f} vs "
+                  f"{float(loss):.6f}, grad rel-L2 {float(arr[pre + 'grad_rel_l2']):.4f} cosine {float(arr[pre + 'grad_cosine']):.5f}")
         if with_autocast:
             # the REFERENCE itself under bf16 autocast (its own fp32 <-> bf16 drift in train mode: the evidence the stated
             # tolerance of the HIP path is anchored in)
@@ -368,13 +389,13 @@ SEEDED = {
     # BASELINE configs[1] at the benchmark's own batch (the kernel plan the driver times): base_ch 64 + skip LSTMs, B=32
     "ref_cfg1_b32": dict(base_ch=64, skip=True, B=32, T=2, HW=64, kind="uniform", seed=900, use_mask=False),
     # well-sized autocast anchor (BatchNorm statistics over >= 256 values per channel at every level)
-    "ref_autocast_b16": dict(base_ch=8, skip=True, B=16, T=3, HW=64, kind="uniform", seed=910, use_mask=True),
+    "ref_autocast_b16": dict(base_ch=8, skip=True, B=16, T=3, HW=64, kind="uniform", seed=910, use_mask=True, with_fp16=True),
     # Moving-MNIST-shaped blobs through the full model
     "ref_blobs64": dict(base_ch=16, skip=True, B=8, T=4, HW=64, kind="blobs", seed=920, use_mask=True),
     # configs[2]: cloud 128x128
     "ref_cloud128": dict(base_ch=16, skip=True, B=4, T=3, HW=128, kind="blobs", seed=930, use_mask=True),
     # configs[3]: 256x256
-    "ref_256": dict(base_ch=8, skip=True, B=2, T=2, HW=256, kind="uniform", seed=940, use_mask=False),
+    "ref_256": dict(base_ch=8, skip=True, B=2, T=2, HW=256, kind="uniform", seed=940, use_mask=False, with_fp16=True),
     # configs[4]: 512x512 rollout (inference only)
     # (seed 950 draws an output head whose terms cancel: |out| = 0.004 against activations of 0.3, so the same absolute error
     #  as every other case -- 4e-5 -- reads as rel-L2 1.05e-2 there; 952 is the next seed whose |out| is of the activations' order)

@@ -17,7 +17,9 @@ from .optim import FusedAdamW
 from .engine import train_one_epoch, evaluate, train_step, SyntheticSequences, NPZSequenceDataset, device_transform
 from .ddp import FlatDDP
 from .streaming import StreamingPredictor
+from .ops import compute_dtype, set_compute_dtype, get_compute_dtype
 
 __all__ = ["ConvLSTMCell", "ConvLSTM", "DoubleConv", "Down", "Up", "OutConv", "SpatialAttention",
            "TemporalUNetDualView", "UNet", "compute_loss", "FusedAdamW", "train_one_epoch", "evaluate",
-           "train_step", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "StreamingPredictor", "UclstmError", "ops"]
+           "train_step", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "StreamingPredictor", "UclstmError", "ops",
+           "compute_dtype", "set_compute_dtype", "get_compute_dtype"]

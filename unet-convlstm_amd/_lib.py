@@ -112,6 +112,8 @@ _PROTOS = {
     "uclstm_loss_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "uclstm_sumsq": [_P, _L, _P, _P],
     "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
+    "uclstm_adamw_step_scaled": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P],
+    "uclstm_loss_scale_update": [_P, _P, _F, _F, _I, _P],
     "uclstm_dataset_transform": [_P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _F, _F, _F, _P],
     "uclstm_metric_sums": [_P, _P, _P, _P, _L, _F, _F, _F, _P],
     "uclstm_stream_spin": [_I, _P],
@@ -122,11 +124,17 @@ _PROTOS = {
 _RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64}
 
 
+# entry points that exist twice: name (bfloat16) and name_f16 (IEEE binary16), identical signatures (include/uclstm.h)
+F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum']
+
+
 def header_symbols() -> list[str]:
-    """Every function name declared in include/uclstm.h."""
+    """Every function name declared in include/uclstm.h (the fp16 twins are declared through UCLSTM_F16_TWIN(name))."""
     with open(HEADER_PATH) as f:
         text = f.read()
-    return sorted(set(re.findall(r"\b(uclstm_[a-z0-9_]+)\s*\(", text)))
+    names = set(re.findall(r"\b(uclstm_[a-z0-9_]+)\s*\(", text))
+    names |= {n + "_f16" for n in re.findall(r"^UCLSTM_F16_TWIN\((uclstm_[a-z0-9_]+)\)", text, re.M)}
+    return sorted(names)
 
 
 def _load() -> C.CDLL:
@@ -135,19 +143,41 @@ def _load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python unet-convlstm_amd/build.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for this package.")
     lib = C.CDLL(LIB_PATH)
-    for name, argtypes in _PROTOS.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError as e:
-            raise UclstmError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
-        fn.argtypes = argtypes
-        fn.restype = _RESTYPES.get(name, C.c_int32)
+    for name, argtypes in list(_PROTOS.items()):
+        for sym in ([name, name + "_f16"] if name in F16_TWINS else [name]):
+            try:
+                fn = getattr(lib, sym)
+            except AttributeError as e:
+                raise UclstmError(f"{LIB_PATH} does not export {sym}; rebuild the library") from e
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int32)
     if lib.uclstm_abi_version() != ABI_VERSION:
         raise UclstmError("libuclstm.so ABI version mismatch; rebuild the library")
     return lib
 
 
 lib = _load()
+
+
+class _F16Kernels:
+    """The same entry points for IEEE binary16 activations: twins resolve to ``name_f16``, shared ones to ``name``."""
+
+    def __getattr__(self, name):
+        fn = getattr(lib, name + "_f16" if name in F16_TWINS else name)
+        setattr(self, name, fn)
+        return fn
+
+
+lib16 = _F16Kernels()
+
+
+def kernels(dtype):
+    """Kernel set for a 16-bit activation dtype: ``torch.bfloat16`` -> ``lib``, ``torch.float16`` -> ``lib16``."""
+    if dtype == torch.bfloat16:
+        return lib
+    if dtype == torch.float16:
+        return lib16
+    raise UclstmError(f"activations must be torch.bfloat16 or torch.float16, got {dtype}")
 
 
 def check(rc: int, what: str) -> None:

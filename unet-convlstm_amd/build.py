@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libuclstm.so")
 SOURCES = ["igemm_fwd.hip", "igemm_wgrad.hip", "pointwise.hip", "pack.hip", "loss_optim.hip"]
+# the sources that touch 16-bit activations / panels are compiled a second time for IEEE binary16 (entry points *_f16)
+F16_SOURCES = ["igemm_fwd.hip", "igemm_wgrad.hip", "pointwise.hip", "pack.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
@@ -40,16 +42,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job) -> str:
+        src, f16 = job
+        obj = os.path.join(objdir, src.replace(".hip", "_f16.o" if f16 else ".o"))
+        cmd = [hipcc, *FLAGS, *(["-DUCLSTM_ACT_F16", "-Wno-unused-function"] if f16 else []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    jobs = [(s, False) for s in SOURCES] + [(s, True) for s in F16_SOURCES]
+    with ThreadPoolExecutor(max_workers=5) as ex:
+        objs = list(ex.map(compile_one, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)

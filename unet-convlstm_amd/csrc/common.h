@@ -2,11 +2,44 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// The 16-bit storage / MFMA operand type of activations and weight panels.  The dtype-dependent sources (igemm_fwd,
+// igemm_wgrad, pointwise, pack) are compiled TWICE into the same library: once for bfloat16 (the default entry points) and
+// once with -DUCLSTM_ACT_F16 for IEEE binary16, whose entry points carry the suffix _f16 (include/uclstm.h, "fp16 twins":
+// BASELINE.json configs[3] asks for fp16 MFMA).  Accumulators, cell state, statistics and all gradients of parameters stay
+// f32 in both.  Entry points that do not touch 16-bit data exist once (guarded by #ifndef UCLSTM_ACT_F16 in their files).
+#if defined(UCLSTM_ACT_F16)
+#define uclstm_igemm_fwd uclstm_igemm_fwd_f16
+#define uclstm_igemm_wgrad uclstm_igemm_wgrad_f16
+#define uclstm_pack_weights uclstm_pack_weights_f16
+#define uclstm_bn_apply_relu uclstm_bn_apply_relu_f16
+#define uclstm_bn_bwd_reduce uclstm_bn_bwd_reduce_f16
+#define uclstm_bn_bwd_apply uclstm_bn_bwd_apply_f16
+#define uclstm_maxpool2_fwd uclstm_maxpool2_fwd_f16
+#define uclstm_maxpool2_bwd uclstm_maxpool2_bwd_f16
+#define uclstm_lstm_bwd_pointwise uclstm_lstm_bwd_pointwise_f16
+#define uclstm_lstm_fwd_pointwise uclstm_lstm_fwd_pointwise_f16
+#define uclstm_nchw_to_nhwc uclstm_nchw_to_nhwc_f16
+#define uclstm_nhwc_to_nchw uclstm_nhwc_to_nchw_f16
+#define uclstm_nchw_grad_to_nhwc uclstm_nchw_grad_to_nhwc_f16
+#define uclstm_im2col3x3_first uclstm_im2col3x3_first_f16
+#define uclstm_outconv_fwd uclstm_outconv_fwd_f16
+#define uclstm_outconv_bwd uclstm_outconv_bwd_f16
+#define uclstm_colsum uclstm_colsum_f16
+#endif
 #include "../../include/uclstm.h"
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#if defined(UCLSTM_ACT_F16)
+typedef _Float16 act16;
+typedef __attribute__((ext_vector_type(8))) _Float16 act16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 act16x4;
+#define UCLSTM_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 act16;
+typedef __attribute__((ext_vector_type(8))) __bf16 act16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 act16x4;
+#define UCLSTM_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -14,6 +47,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Launch and report only THIS launch's error: the per-thread "last error" may hold a stale, already
 // handled code from another library's HIP call (observed: a launch right after torch's own copies).
+#if defined(UCLSTM_ACT_F16)
+#define g_uclstm_last_hip_error g_uclstm_last_hip_error_f16_
+#endif
 inline int g_uclstm_last_hip_error = 0;      // hipError_t of the most recent failed launch (diagnostics)
 #define UCLSTM_LAUNCH(...)                                      \
     do {                                                        \
@@ -26,19 +62,19 @@ inline int g_uclstm_last_hip_error = 0;      // hipError_t of the most recent fa
         }                                                       \
     } while (0)
 
-__device__ __forceinline__ float bf16_to_f32(bf16 v) { return (float)v; }
-__device__ __forceinline__ bf16 f32_to_bf16(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32: RNE, NaN preserved
+__device__ __forceinline__ float act_to_f32(act16 v) { return (float)v; }
+__device__ __forceinline__ act16 f32_to_act(float v) { return (act16)v; }   // v_cvt_pk_bf16_f32 / v_cvt_f16_f32: RNE, NaN preserved
 
-// 8 bf16 <-> 8 floats through one 16-byte register quad
+// 8 act16 <-> 8 floats through one 16-byte register quad
 union Pack16 {
     uint4 u;
-    bf16x8 v;
-    bf16 e[8];
+    act16x8 v;
+    act16 e[8];
 };
 union Pack8 {
     uint2 u;
-    bf16x4 v;
-    bf16 e[4];
+    act16x4 v;
+    act16 e[4];
 };
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                 }
                 const int toff = (tap / 3 - 1) * W1 + (tap % 3 - 1);
                 const unsigned char* const Wt = Wring + slot * WSLOT;
-                bf16x8 wf[4], xf[4];
+                act16x8 wf[4], xf[4];
                 int xaddr[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -291,14 +291,14 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + (choffw ^ (h << 6)));
+                    for (int a = 0; a < 4; ++a) wf[a] = *(const act16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + (choffw ^ (h << 6)));
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(P + (xaddr[b] ^ (h << 6)));
+                    for (int b = 0; b < 4; ++b) xf[b] = *(const act16x8*)(P + (xaddr[b] ^ (h << 6)));
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = UCLSTM_MFMA_16x16x32(wf[a], xf[b], acc[a][b], 0, 0, 0);
                 }
                 slot = slot + 1 >= 3 ? 0 : slot + 1;
             }
@@ -433,28 +433,28 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         constexpr bool ISSUE = decltype(issue_tag)::value;
         const unsigned char* X = smem + buf * SH::STAGE;
         const unsigned char* Wt = X + SH::XBYTES;
-        bf16x8 wf[4], xf[4];
+        act16x8 wf[4], xf[4];
         const int choff0 = ((0 * 4 + lq) ^ (l15 & 7)) << 4;
         const int choff1 = ((1 * 4 + lq) ^ (l15 & 7)) << 4;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff0);
+        for (int a = 0; a < 4; ++a) wf[a] = *(const act16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff0);
+        for (int b = 0; b < 4; ++b) xf[b] = *(const act16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff0);
         if constexpr (ISSUE) issue_loads(buf ^ 1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = UCLSTM_MFMA_16x16x32(wf[a], xf[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) wf[a] = *(const bf16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff1);
+        for (int a = 0; a < 4; ++a) wf[a] = *(const act16x8*)(Wt + (wc * 64 + a * 16 + l15) * 128 + choff1);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) xf[b] = *(const bf16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff1);
+        for (int b = 0; b < 4; ++b) xf[b] = *(const act16x8*)(X + (wpx * 64 + b * 16 + l15) * 128 + choff1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = UCLSTM_MFMA_16x16x32(wf[a], xf[b], acc[a][b], 0, 0, 0);
         if constexpr (ISSUE) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -520,16 +520,16 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                         const float vg = fast_tanh(acc[2][b][r] + xa[2][r] + bg[2][r]);
                         const float vo = fast_sigmoid(acc[3][b][r] + xa[3][r] + bg[3][r]);
                         cn[r] = vf * cp[r] + vi * vg;                 // train/unet.py:34
-                        hi.e[r] = f32_to_bf16(vo * fast_tanh(cn[r])); // train/unet.py:35
-                        gi.e[r] = f32_to_bf16(vi);
-                        gf.e[r] = f32_to_bf16(vf);
-                        gg.e[r] = f32_to_bf16(vg);
-                        go.e[r] = f32_to_bf16(vo);
+                        hi.e[r] = f32_to_act(vo * fast_tanh(cn[r])); // train/unet.py:35
+                        gi.e[r] = f32_to_act(vi);
+                        gf.e[r] = f32_to_act(vf);
+                        gg.e[r] = f32_to_act(vg);
+                        go.e[r] = f32_to_act(vo);
                     }
                     *(float4*)(d.c_out + pix * d.Hd_p + hc) = make_float4(cn[0], cn[1], cn[2], cn[3]);
-                    *(uint2*)((bf16*)d.h_out + pix * d.Hd_p + hc) = hi.u;
+                    *(uint2*)((act16*)d.h_out + pix * d.Hd_p + hc) = hi.u;
                     if (d.gates_out) {
-                        bf16* gp = (bf16*)d.gates_out + pix * 4 * d.Hd_p + hc;
+                        act16* gp = (act16*)d.gates_out + pix * 4 * d.Hd_p + hc;
                         *(uint2*)(gp) = gi.u;
                         *(uint2*)(gp + d.Hd_p) = gf.u;
                         *(uint2*)(gp + 2 * d.Hd_p) = gg.u;
@@ -592,9 +592,9 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                 for (int r = 0; r < 4; ++r) {
                     float v = (acc[a][b][r] + bs[r]) * sc[r] + sh[r];
                     if (d.relu) v = fmaxf(v, 0.f);
-                    o.e[r] = f32_to_bf16(v);
+                    o.e[r] = f32_to_act(v);
                     if constexpr (SHP == 2) {      // statistics of the ROUNDED values (what BatchNorm will read), from registers
-                        const float q = prow < rows_valid ? bf16_to_f32(o.e[r]) : 0.f;
+                        const float q = prow < rows_valid ? act_to_f32(o.e[r]) : 0.f;
                         ps1[r] += q;
                         ps2[r] += q * q;
                     }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                     s2 = Red[((2 * half) * TBN + col) * 2 + 1] + Red[((2 * half + 1) * TBN + col) * 2 + 1];
                 } else {
                     for (int r = 0; r < rows_valid; ++r) {
-                        const float v = bf16_to_f32(*(const bf16*)(Ot + r * OT_PITCH + col * 2));
+                        const float v = act_to_f32(*(const act16*)(Ot + r * OT_PITCH + col * 2));
                         s1 += v;
                         s2 += v * v;
                     }
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                     const int yd = y * sg.scale + sg.oy;
                     const int xd = x * sg.scale + sg.ox;
                     if ((unsigned)yd < (unsigned)sg.Hd && (unsigned)xd < (unsigned)sg.Wd) {
-                        bf16* dst = (bf16*)sg.ptr + (((long)img * sg.Hd + yd) * sg.Wd + xd) * (long)sg.C + sg.c_off + (n - sg.n_begin);
+                        act16* dst = (act16*)sg.ptr + (((long)img * sg.Hd + yd) * sg.Wd + xd) * (long)sg.C + sg.c_off + (n - sg.n_begin);
                         *(uint4*)dst = *(const uint4*)(Ot + r * OT_PITCH + cc * 16);
                     }
                 }
@@ -858,14 +858,14 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         const unsigned char* rowp[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) rowp[dy] = Ring + ((v0 + wave + dy) % C64_SLOTS) * C64_ROW;      // virtual row v0 + wave + dy - 1
-        bf16x8 wf[2][4], xf[2][4];
+        act16x8 wf[2][4], xf[2][4];
         auto load_step = [&](int st, int set) {
             const int tp = st >> 1, kk = st & 1;
             const int dy = tp / 3, dx = tp - dy * 3;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[set][a] = *(const bf16x8*)(Wl + tp * 8192 + a * 2048 + woff[kk]);
+            for (int a = 0; a < 4; ++a) wf[set][a] = *(const act16x8*)(Wl + tp * 8192 + a * 2048 + woff[kk]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xf[set][b] = *(const bf16x8*)(rowp[dy] + xoff[b][dx][kk]);
+            for (int b = 0; b < 4; ++b) xf[set][b] = *(const act16x8*)(rowp[dy] + xoff[b][dx][kk]);
         };
         load_step(0, 0);
 #pragma unroll
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st & 1][a], xf[st & 1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = UCLSTM_MFMA_16x16x32(wf[st & 1][a], xf[st & 1][b], acc[a][b], 0, 0, 0);
             if (st + 1 < 18) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -889,9 +889,9 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
         // ---- epilogue from registers: wave = image row y, lane = (pixel b*16 + l15, channels a*16 + lq*4 .. +3) ----
         const int y = 4 * tr + wave;
         const int img = k / strips, strip = k - img * strips;
-        bf16* orow = (bf16*)sg.ptr + ((long)(img * H + y) * d.W + strip * 64) * (long)sg.C + sg.c_off;
+        act16* orow = (act16*)sg.ptr + ((long)(img * H + y) * d.W + strip * 64) * (long)sg.C + sg.c_off;
         float s1[4][4], s2[4][4];
-        Pack8 ov[4][4];           // [a][b]: this lane's 4 channels of pixel b*16 + l15, bf16
+        Pack8 ov[4][4];           // [a][b]: this lane's 4 channels of pixel b*16 + l15, act16
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -902,8 +902,8 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
                 for (int r = 0; r < 4; ++r) {
                     float v = (acc[a][b][r] + bs[a][r]) * scl[a][r] + sft[a][r];
                     if (d.relu) v = fmaxf(v, 0.f);
-                    ov[a][b].e[r] = f32_to_bf16(v);
-                    const float q = bf16_to_f32(ov[a][b].e[r]);
+                    ov[a][b].e[r] = f32_to_act(v);
+                    const float q = act_to_f32(ov[a][b].e[r]);
                     s1[a][r] += q;
                     s2[a][r] += q * q;
                 }
@@ -1053,19 +1053,23 @@ int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipS
 
 }  // namespace
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_t W, int32_t groups, int32_t N) {
     if (groups <= 0 || n_img <= 0 || n_img % groups || N <= 0) return UCLSTM_E_BADARG;
     const int64_t mg = (int64_t)(n_img / groups) * H * W;
     const int bm = shape_pixels(pick_shape(N, mg, groups, UCLSTM_EPI_STORE));
     return (int32_t)((mg + bm - 1) / bm);
 }
+#endif
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit) {
     if (Ktot <= 0 || (Ktot % BK) || ksplit < 1) return UCLSTM_E_BADARG;
     const int ksteps = Ktot / BK;
     const int kper = (ksteps + ksplit - 1) / ksplit;
     return (ksteps + kper - 1) / kper;
 }
+#endif
 
 // Validation + launch plan shared by uclstm_igemm_fwd and uclstm_igemm_fwd_shape: derived constants, block shape, grid.
 static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64_t& nblk, int64_t& mg_out) {
@@ -1147,6 +1151,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     return UCLSTM_OK;
 }
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_igemm_fwd_shape(const uclstm_igemm_desc* dp) {
     if (!dp) return UCLSTM_E_BADARG;
     Derived dv;
@@ -1156,6 +1161,7 @@ extern "C" int32_t uclstm_igemm_fwd_shape(const uclstm_igemm_desc* dp) {
     if (rc != UCLSTM_OK) return rc;
     return (c64_ok(*dp) && mg % 256 == 0) ? 3 : shp;
 }
+#endif
 
 extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (!dp) return UCLSTM_E_BADARG;

@@ -44,12 +44,12 @@ typedef __attribute__((address_space(3))) short4v* lds_s4p;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+__device__ __forceinline__ act16x8 tr_frag(const unsigned char* p) {
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p));
     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p + 16 * PITCH));
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(act16x8, v);
 }
 
 // addr = ok ? addr : zero (branch-free: the DMA below must stay ONE full-wave instruction)
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const uclstm_wgrad_
         const unsigned char* X = Y + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 yf[4], xf[4];
+            act16x8 yf[4], xf[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) yf[a] = tr_frag(Y + ks * 32 * PITCH + goffy[a]);
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const uclstm_wgrad_
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = UCLSTM_MFMA_16x16x32(yf[a], xf[b], acc[a][b], 0, 0, 0);
         }
     };
 
@@ -270,12 +270,12 @@ struct WShape {
     static constexpr int NI = 2 * NPL;                        // DMA instructions per wave per stage (8 per plane / 4 waves)
 };
 
-__device__ __forceinline__ bf16x8 tr_frag128(const unsigned char* p) {
+__device__ __forceinline__ act16x8 tr_frag128(const unsigned char* p) {
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p));
     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(p + 16 * 128));
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(act16x8, v);
 }
 
 template <int WN, int NSRC>
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
         const unsigned char* X = smem + buf * SH::STAGE + (WN + wk) * PLANE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 yf[4], xf[4];
+            act16x8 yf[4], xf[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) yf[a] = tr_frag128(Y + ks * 32 * 128 + goff[a]);
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = UCLSTM_MFMA_16x16x32(yf[a], xf[b], acc[a][b], 0, 0, 0);
         }
     };
 
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
 #pragma unroll
     for (int j = 0; j < 2; ++j) goffB[j] = (wc >> 1) * PLANE + trow * 128 + ((((wc & 1) * 2 + j) ^ tsw) << 5) + (l15 & 3) * 8;
 
-    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+    act16x8 af[4][2], b0f[2][2], b1f[2][2];
 
     // prologue: six half-tiles in flight, the first two (dY-lo, X-lo of K-tile 0) landed before the first phase
 #pragma unroll
@@ -665,8 +665,8 @@ __global__ __launch_bounds__(512, 1) void igemm_wgrad_p3_kernel(const uclstm_wgr
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const bf16x8 bb = nh ? b1f[j][ks] : b0f[j][ks];
-                            acc[mh][i][nh][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bb, acc[mh][i][nh][j], 0, 0, 0);
+                            const act16x8 bb = nh ? b1f[j][ks] : b0f[j][ks];
+                            acc[mh][i][nh][j] = UCLSTM_MFMA_16x16x32(af[i][ks], bb, acc[mh][i][nh][j], 0, 0, 0);
                         }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -905,4 +905,6 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
 
 extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream) { return wgrad_run(d, stream, false); }
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d) { return wgrad_run(d, nullptr, true); }
+#endif

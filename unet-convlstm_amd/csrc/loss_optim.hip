@@ -132,6 +132,54 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
     }
 }
 
+// fp16 training: the gradient buffer holds scale x the true gradient (loss scaling keeps fp16 activation gradients out of the
+// subnormal range).  state = {scale, growth tracker, successful steps}.  Same update as adamw_kernel on g / scale; nothing is
+// touched when the scaled sum of squares is not finite (an overflowed step is skipped, the scale backs off in
+// loss_scale_update_kernel); Adam's bias-correction step is the device-side count of successful steps.
+__global__ void adamw_scaled_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                                    int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2, float eps,
+                                    float wd, const float* __restrict__ state) {
+    const double ss = *sumsq;
+    if (!(ss == ss) || ss > 1.0e300 || isinf(ss)) return;
+    const float inv_scale = 1.f / state[0];
+    const float step = state[2] + 1.f;
+    const float inv_bc1 = 1.f / (1.f - exp2f(step * log2f(b1)));
+    const float inv_sqrt_bc2 = rsqrtf(1.f - exp2f(step * log2f(b2)));
+    float coef = inv_scale;
+    if (max_norm > 0.f) {
+        const float total = (float)sqrt(ss) * inv_scale;
+        coef *= fminf(max_norm / (total + 1e-6f), 1.f);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gi = g[i] * coef;
+        float w = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        w -= lr * inv_bc1 * mi / denom;
+        p[i] = w;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const double* __restrict__ sumsq, float growth, float backoff,
+                                         int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ss = *sumsq;
+    if (!(ss == ss) || isinf(ss)) {
+        state[0] = fmaxf(state[0] * backoff, 1.f);
+        state[1] = 0.f;
+    } else {
+        state[2] += 1.f;
+        state[1] += 1.f;
+        if (state[1] >= (float)interval) {
+            state[0] = fminf(state[0] * growth, 16777216.f);
+            state[1] = 0.f;
+        }
+    }
+}
+
 // NPZSequenceDataset.__getitem__ for a batch (train/unet.py:273-304): mask from RAW channel 0 (> 1.1) before scaling,
 // x / norm_const, y clipped -> asinh(y / scale) -> [-1, 1]
 __global__ void dataset_transform_kernel(const float* __restrict__ xr, const float* __restrict__ yr, float* __restrict__ x,
@@ -213,6 +261,22 @@ extern "C" int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     UCLSTM_LAUNCH(adamw_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_adamw_step_scaled(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
+                                            float lr, float beta1, float beta2, float eps, float weight_decay, const float* scale_state,
+                                            void* stream) {
+    if (!p || !m || !v || !g || n <= 0 || !sumsq || !scale_state) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(adamw_scaled_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
+                  beta2, eps, weight_decay, scale_state);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_loss_scale_update(float* scale_state, const double* sumsq, float growth, float backoff, int32_t interval,
+                                            void* stream) {
+    if (!scale_state || !sumsq || growth < 1.f || backoff <= 0.f || backoff > 1.f || interval < 1) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, sumsq, growth, backoff, interval);
     return UCLSTM_OK;
 }
 

@@ -79,13 +79,13 @@ __device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, const PackD
     return r;
 }
 
-__global__ void pack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w, bf16* __restrict__ wp) {
+__global__ void pack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w, act16* __restrict__ wp) {
     const uint32_t total = (uint32_t)d.N * (uint32_t)d.Ktot;       // < 2^31 (checked by the launcher)
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int n = (int)fdiv(idx, dv.ktot);
         const int k = (int)(idx - (uint32_t)n * (uint32_t)d.Ktot);
         const Decoded r = decode(d, dv, n, k);
-        wp[idx] = f32_to_bf16(r.valid ? w[r.off] : 0.f);
+        wp[idx] = f32_to_act(r.valid ? w[r.off] : 0.f);
     }
 }
 
@@ -120,7 +120,7 @@ __global__ void unpack_kernel(const uclstm_pack_desc d, const PackDiv dv, const 
 // run of channels*taps floats.  Block = (panel row, source, 256-channel chunk).
 template <int TAPS, bool UNPACK>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
-                                                        bf16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
+                                                        act16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
                                                         float* __restrict__ grad, int accumulate, int chunks0) {
     __shared__ float buf[256 * TAPS];
     const int n = blockIdx.y;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int ts = d.tap_flip ? TAPS - 1 - t : t;
-                wp[pbase + (int64_t)t * per_tap] = f32_to_bf16((ok_n && cl < nval) ? buf[cl * TAPS + ts] : 0.f);
+                wp[pbase + (int64_t)t * per_tap] = f32_to_act((ok_n && cl < nval) ? buf[cl * TAPS + ts] : 0.f);
             }
         }
     } else {
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d
 // consecutive panel rows is one contiguous run of 16*taps floats.  Block = 16 panel rows x 64 K columns.
 template <int TAPS>
 __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
-                                                              bf16* __restrict__ wp) {
+                                                              act16* __restrict__ wp) {
     constexpr int RUN = 16 * TAPS;
-    constexpr int PITCH = RUN + 2;                                    // in bf16: 73 dwords per column, odd -> conflict-free column walks
+    constexpr int PITCH = RUN + 2;                                    // in act16: 73 dwords per column, odd -> conflict-free column walks
     constexpr int NLD = 4 * TAPS;                                     // 64 * RUN / 256 loads per thread
-    __shared__ bf16 buf[64 * PITCH];                                  // 18 KiB (already rounded: the panel is bf16), small enough
+    __shared__ act16 buf[64 * PITCH];                                  // 18 KiB (already rounded: the panel is act16), small enough
                                                                       // to share a CU with a 128-KiB weight-gradient block
     __shared__ int64_t kbase[64];
     const int kc0 = blockIdx.x * 64;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
     for (int u = 0; u < NLD; ++u) {
         const int e = u * 256 + threadIdx.x;
         const int kl = e / RUN, r = e - kl * RUN;
-        buf[kl * PITCH + r] = f32_to_bf16(v[u]);
+        buf[kl * PITCH + r] = f32_to_act(v[u]);
     }
     __syncthreads();
     // output: panel row (n0 + nl), tap t, 64 consecutive K columns = 128 contiguous bytes; a lane gathers 8 columns from LDS
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
         const int ts = d.tap_flip ? TAPS - 1 - t : t;
         Pack16 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = nl < nrow ? buf[(g8 * 8 + j) * PITCH + nl * TAPS + ts] : f32_to_bf16(0.f);
-        bf16* dst = wp + (int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + g8 * 8;
+        for (int j = 0; j < 8; ++j) o.e[j] = nl < nrow ? buf[(g8 * 8 + j) * PITCH + nl * TAPS + ts] : f32_to_act(0.f);
+        act16* dst = wp + (int64_t)(n0 + nl) * d.Ktot + (int64_t)t * per_tap + kc0 + g8 * 8;
         if (full) {
             *(uint4*)dst = o.u;
         } else {
@@ -329,23 +329,24 @@ extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w
         const int ch0 = (d->kseg[0] + 255) / 256, ch1 = (d->kseg[1] + 255) / 256;
         const dim3 grid(ch0 + ch1, d->N);
         if (d->taps == 9)
-            UCLSTM_LAUNCH((pack_rows_kernel<9, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp, nullptr, 0,
+            UCLSTM_LAUNCH((pack_rows_kernel<9, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp, nullptr, 0,
                           (int64_t)0, nullptr, 0, ch0);
         else
-            UCLSTM_LAUNCH((pack_rows_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp, nullptr, 0,
+            UCLSTM_LAUNCH((pack_rows_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp, nullptr, 0,
                           (int64_t)0, nullptr, 0, ch0);
         return UCLSTM_OK;
     }
     if (transposed_family(*d)) {
         const dim3 grid((d->kseg[0] + d->kseg[1] + 63) / 64, (d->N + 15) / 16);
-        if (d->taps == 9) UCLSTM_LAUNCH(pack_transposed_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
-        else UCLSTM_LAUNCH(pack_transposed_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
+        if (d->taps == 9) UCLSTM_LAUNCH(pack_transposed_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp);
+        else UCLSTM_LAUNCH(pack_transposed_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp);
         return UCLSTM_OK;
     }
-    UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (bf16*)wp);
+    UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp);
     return UCLSTM_OK;
 }
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* dwp, int32_t nslab, int64_t slab, float* grad,
                                        int32_t accumulate, void* stream) {
     if (!desc_ok(d) || !dwp || !grad || nslab < 1 || (nslab > 1 && slab < (int64_t)d->N * d->Ktot)) return UCLSTM_E_BADARG;
@@ -379,9 +380,12 @@ extern "C" int32_t uclstm_unpack_wgrad(const uclstm_pack_desc* d, const float* d
     UCLSTM_LAUNCH(unpack_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), dwp, nslab, slab, grad, accumulate);
     return UCLSTM_OK;
 }
+#endif
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, void* stream) {
     if (!desc_ok(d) || !b || !bp) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(pack_bias_kernel, dim3((d->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), b, bp);
     return UCLSTM_OK;
 }
+#endif

@@ -1,6 +1,6 @@
 // HBM-bound kernels around the MFMA GEMMs: BatchNorm(+ReLU) finalize/apply/backward, MaxPool2d(2),
 // the ConvLSTM backward point-wise part, layout conversion at the module boundary, OutConv 1x1 and
-// column sums.  All move 16 bytes (8 bf16 channels) per lane per access on NHWC tensors; reductions
+// column sums.  All move 16 bytes (8 act16 channels) per lane per access on NHWC tensors; reductions
 // over pixels keep a fixed channel chunk per thread, reduce across the block in LDS and finish with
 // one f32 atomic per (block, channel).
 #include "common.h"
@@ -14,12 +14,12 @@ __device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
     Pack16 p;
     p.u = u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(p.e[i]);
+    for (int i = 0; i < 8; ++i) f[i] = act_to_f32(p.e[i]);
 }
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     Pack16 p;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p.e[i] = f32_to_bf16(f[i]);
+    for (int i = 0; i < 8; ++i) p.e[i] = f32_to_act(f[i]);
     return p.u;
 }
 __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
@@ -153,7 +153,7 @@ static ColGeom col_geom(int Cp) {
 
 // partials[g*blocks_per_group + bi][c][0..1] = this block's (sum g_, sum g_*xhat).  No atomics: the run-to-run order of f32
 // atomic adds here changed the whole gradient by ~1e-3 (the sums feed dz, and BatchNorm backward at random init amplifies
-// 1e-7 perturbations through its bf16 roundings layer after layer); bn_bwd_sum_kernel adds the rows in a fixed order.
+// 1e-7 perturbations through its act16 roundings layer after layer); bn_bwd_sum_kernel adds the rows in a fixed order.
 __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, float* __restrict__ partials, int64_t ppg, int Cp, ColGeom cg,
@@ -409,8 +409,8 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
 __global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ pre_add,
                                    const float* __restrict__ bias,
-                                   const float* __restrict__ c_prev, float* __restrict__ c_out, bf16* __restrict__ h_out,
-                                   bf16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
+                                   const float* __restrict__ c_prev, float* __restrict__ c_out, act16* __restrict__ h_out,
+                                   act16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
     for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
         const uint32_t pix = fdiv((uint32_t)idx, dq);
         const int hc = ((uint32_t)idx - pix * dq.d) * 4;                 // first hidden channel of the quad
@@ -440,13 +440,13 @@ __global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clea
             const float vi = fast_sigmoid(g4[0][r]), vf = fast_sigmoid(g4[1][r]);
             const float vg = fast_tanh(g4[2][r]), vo = fast_sigmoid(g4[3][r]);
             cn[r] = vf * cp[r] + vi * vg;
-            hi.e[r] = f32_to_bf16(vo * fast_tanh(cn[r]));
-            gi.e[r] = f32_to_bf16(vi); gf.e[r] = f32_to_bf16(vf); gg.e[r] = f32_to_bf16(vg); go.e[r] = f32_to_bf16(vo);
+            hi.e[r] = f32_to_act(vo * fast_tanh(cn[r]));
+            gi.e[r] = f32_to_act(vi); gf.e[r] = f32_to_act(vf); gg.e[r] = f32_to_act(vg); go.e[r] = f32_to_act(vo);
         }
         *(float4*)(c_out + so) = make_float4(cn[0], cn[1], cn[2], cn[3]);
         *(uint2*)(h_out + so) = hi.u;
         if (gates_out) {
-            bf16* gp = gates_out + (int64_t)pix * 4 * Hd_p + hc;
+            act16* gp = gates_out + (int64_t)pix * 4 * Hd_p + hc;
             *(uint2*)(gp) = gi.u;
             *(uint2*)(gp + Hd_p) = gf.u;
             *(uint2*)(gp + 2 * Hd_p) = gg.u;
@@ -739,7 +739,7 @@ __global__ void outconv_bwd_dw_kernel(const uint4* __restrict__ a, const float* 
     }
 }
 
-// Column sums of a [pixels][Cp] bf16 tensor (bias gradients).  grid.x = pixel ranges, grid.y = groups of NT 16-byte
+// Column sums of a [pixels][Cp] act16 tensor (bias gradients).  grid.x = pixel ranges, grid.y = groups of NT 16-byte
 // column chunks; a thread owns one chunk column of `rows` interleaved pixel rows and keeps four loads in flight.
 __global__ void colsum_kernel(const uint4* __restrict__ a, float* __restrict__ out, int64_t pixels, ColGeom cg, int Cp,
                               int64_t pix_per_block) {
@@ -790,6 +790,7 @@ bool aligned16(const void* p) { return p && ((uintptr_t)p % 16) == 0; }
 }  // namespace
 
 // =============================================================================================
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                                       int64_t count_per_group, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
@@ -807,6 +808,7 @@ extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tile
                   unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     return UCLSTM_OK;
 }
+#endif
 
 extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift, int64_t pixels,
                                         int64_t pixels_per_group, int32_t Cp, void* stream) {
@@ -828,11 +830,13 @@ inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
 }
 }  // namespace
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_group) {
     if (pixels <= 0 || pixels_per_group <= 0 || (pixels % pixels_per_group)) return UCLSTM_E_BADARG;
     const int groups = (int)(pixels / pixels_per_group);
     return (int64_t)groups * bn_bwd_blocks_per_group(pixels_per_group, groups);
 }
+#endif
 
 extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* partials, float* sums, int64_t pixels, int64_t pixels_per_group,
@@ -878,6 +882,7 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
     return UCLSTM_OK;
 }
 
+namespace {
 __global__ void bn_bwd_param_grads_kernel(const float* __restrict__ sums, int groups, int Cp, int C, float* __restrict__ dgamma,
                                           float* __restrict__ dbeta, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,7 +896,9 @@ __global__ void bn_bwd_param_grads_kernel(const float* __restrict__ sums, int gr
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
 }
+}  // namespace
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, int32_t Cp, int32_t C, float* dgamma, float* dbeta,
                                              int32_t accumulate, void* stream) {
     if (!sums || !dgamma || !dbeta || groups <= 0 || Cp <= 0 || C <= 0 || C > Cp) return UCLSTM_E_BADARG;
@@ -899,6 +906,7 @@ extern "C" int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, 
                   dbeta, accumulate);
     return UCLSTM_OK;
 }
+#endif
 
 extern "C" int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, int32_t W, int32_t Cp, void* stream) {
     if (!aligned16(a) || !aligned16(p) || n_img <= 0 || H < 2 || W < 2 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
@@ -932,8 +940,8 @@ extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t 
     if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     const int N = 64 * ((Hd_p + 15) / 16);
     if (nslab > 1 && (slab <= 0 || (slab % 4))) return UCLSTM_E_BADARG;
-    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, pre_add, bias, c_prev, c_out, (bf16*)h_out,
-                  (bf16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
+    UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, pre_add, bias, c_prev, c_out, (act16*)h_out,
+                  (act16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
     return UCLSTM_OK;
 }
 
@@ -978,6 +986,7 @@ extern "C" int32_t uclstm_nhwc_to_nchw(const void* a, float* out, int32_t n_img,
     return UCLSTM_OK;
 }
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_nchw_to_nhwc_f32(const float* x, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
                                            void* stream) {
     if (!x || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
@@ -987,7 +996,9 @@ extern "C" int32_t uclstm_nchw_to_nhwc_f32(const float* x, float* out, int32_t n
                        make_fastdiv(H * W), make_fastdiv(Cp));
     return UCLSTM_OK;
 }
+#endif
 
+#ifndef UCLSTM_ACT_F16
 extern "C" int32_t uclstm_nhwc_to_nchw_f32(const float* a, float* out, int32_t n_img, int32_t C, int32_t Cp, int32_t H, int32_t W,
                                            void* stream) {
     if (!a || !out || n_img <= 0 || C <= 0 || Cp < C || H <= 0 || W <= 0) return UCLSTM_E_BADARG;
@@ -997,6 +1008,7 @@ extern "C" int32_t uclstm_nhwc_to_nchw_f32(const float* a, float* out, int32_t n
                        make_fastdiv(H * W), make_fastdiv(C));
     return UCLSTM_OK;
 }
+#endif
 
 extern "C" int32_t uclstm_im2col3x3_first(const float* x, void* out, int32_t n_img, int32_t C, int32_t Kp, int32_t H, int32_t W,
                                           int32_t inner, int64_t inner_stride, int64_t outer_stride, void* stream) {

@@ -188,7 +188,8 @@ def train_step(model, optimizer, x, y, mask=None, use_mask=True, ddp=None, clip_
         output, _ = model(x)
         y_pred = _stack(output)
         loss = compute_loss(y_pred, y, mask, use_mask)
-        loss.backward()
+        # fp16 compute: backward runs on loss * scale (FusedAdamW(loss_scale=...) owns the device-side dynamic scale)
+        (optimizer.scale_loss(loss) if hasattr(optimizer, "scale_loss") else loss).backward()
     finally:
         if on_gpu:
             ops.prepack_end()

@@ -17,7 +17,44 @@ import torch
 from . import _lib as L
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
+ACT = (BF16, F16)          # the 16-bit activation / panel dtypes; every operator takes its kernel set from its input's dtype
+
+# Compute dtype of NEW activation tensors at the module boundary (f32 NCHW in -> 16-bit NHWC): bfloat16 by default,
+# torch.float16 = the fp16-MFMA twin kernels (BASELINE.json configs[3]).  Downstream operators follow their input's dtype.
+_COMPUTE_DTYPE = BF16
+
+
+def set_compute_dtype(dtype) -> None:
+    global _COMPUTE_DTYPE
+    if dtype not in ACT:
+        raise L.UclstmError(f"compute dtype must be torch.bfloat16 or torch.float16, got {dtype}")
+    _COMPUTE_DTYPE = dtype
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+class compute_dtype:
+    """``with ops.compute_dtype(torch.float16): out, _ = model(x)`` -- the forward pass inside runs on the fp16 kernels (the
+    backward pass follows the dtype of the saved activations, wherever it runs)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _COMPUTE_DTYPE
+        set_compute_dtype(self.dtype)
+
+    def __exit__(self, *exc):
+        set_compute_dtype(self.prev)
+
+
+def _k(t: torch.Tensor):
+    """Kernel set (bf16 / fp16 twins) for a 16-bit activation tensor."""
+    return L.kernels(t.dtype)
 
 
 def cpad(c: int) -> int:
@@ -35,7 +72,7 @@ def _stream():
 def _dev(t: torch.Tensor, dtype=None, what: str = "tensor") -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise L.UclstmError(f"{what}: a HIP device tensor is required (this package has no CPU path)")
-    if dtype is not None and t.dtype != dtype:
+    if dtype is not None and (t.dtype not in dtype if isinstance(dtype, tuple) else t.dtype != dtype):
         raise L.UclstmError(f"{what}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise L.UclstmError(f"{what}: must be contiguous")
@@ -87,7 +124,7 @@ class SrcView:
     """One input of a convolution: NHWC bf16 tensor placed at (offY, offX) in the output frame."""
 
     def __init__(self, t: torch.Tensor, offY: int = 0, offX: int = 0):
-        _dev(t, BF16, "conv source")
+        _dev(t, ACT, "conv source")
         assert t.dim() == 4 and t.shape[3] % 8 == 0
         self.t, self.offY, self.offX = t, offY, offX
 
@@ -314,8 +351,8 @@ def prepack_begin() -> None:
         for key, desc, w, off in plan:
             if key in _PACK_READY or w.data_ptr() != key[0]:
                 continue
-            wp = torch.empty((desc.N, desc.Ktot), dtype=BF16, device=w.device)
-            L.check(L.lib.uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * off), _p(wp), _stream()), "pack_weights")
+            wp = torch.empty((desc.N, desc.Ktot), dtype=key[3], device=w.device)
+            L.check(L.kernels(key[3]).uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * off), _p(wp), _stream()), "pack_weights")
             wp.record_stream(main)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -329,11 +366,12 @@ def prepack_end() -> None:
     _PACK_RECORDING = False
 
 
-def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0) -> torch.Tensor:
+def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0, dtype=BF16) -> torch.Tensor:
+    """f32 reference-layout weight -> 16-bit panel of ``dtype`` (the dtype of the activations it will multiply)."""
     _dev(w, F32, "weight")
     key = None
     if _PACK_RECORDING:
-        key = (w.data_ptr(), elem_offset, bytes(desc))
+        key = (w.data_ptr(), elem_offset, bytes(desc), dtype)
         d2 = L.PackDesc()
         C.memmove(C.byref(d2), C.byref(desc), C.sizeof(L.PackDesc))
         _PACK_PLAN.append((key, d2, w, elem_offset))
@@ -347,12 +385,12 @@ def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0) -> tor
         if cache.stale():
             raise L.UclstmError("PanelCache: the weights changed (optimiser step) while a panel cache was current; its owner "
                                 "must drop it first (StreamingPredictor does so in step())")
-        key = (w.data_ptr(), elem_offset, bytes(desc))
+        key = (w.data_ptr(), elem_offset, bytes(desc), dtype)
         hit = cache.entries.get(key)
         if hit is not None and hit[0] == w._version:
             return hit[1]
-    wp = torch.empty((desc.N, desc.Ktot), dtype=BF16, device=w.device)
-    L.check(L.lib.uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * elem_offset), _p(wp), _stream()), "pack_weights")
+    wp = torch.empty((desc.N, desc.Ktot), dtype=dtype, device=w.device)
+    L.check(L.kernels(dtype).uclstm_pack_weights(C.byref(desc), C.c_void_p(w.data_ptr() + 4 * elem_offset), _p(wp), _stream()), "pack_weights")
     if key is not None:
         cache.entries[key] = (w._version, wp)
     return wp
@@ -553,6 +591,12 @@ def _bytes_per_img(t: torch.Tensor) -> int:
     return t[0].numel() * t.element_size()
 
 
+def _same_act_dtype(tensors, what: str) -> None:
+    dt = tensors[0].dtype
+    if dt not in ACT or any(t.dtype != dt for t in tensors):
+        raise L.UclstmError(f"{what}: activations, panels and outputs must share one 16-bit dtype, got {[str(t.dtype) for t in tensors]}")
+
+
 def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, segs, *, ktap: int, scale: int = 1,
                 pad: int = 0, groups: int = 1, bias=None, col_scale=None, col_shift=None, relu: bool = False, stats=None) -> None:
     """segs: list of (tensor, n_begin, n_end, c_off, scale, oy, ox).  ``stats``: [groups, tiles_per_group, N, 2]."""
@@ -584,7 +628,9 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
     d.stats = None if stats is None else stats.data_ptr()
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
     _log_shape(d)
-    _timed("igemm_fwd_store", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
+    _same_act_dtype([sv.t for sv in srcs] + [wp] + [sg[0] for sg in segs], "igemm_fwd(store)")
+    K = _k(wp)
+    _timed("igemm_fwd_store", flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}")
 
 
@@ -624,7 +670,9 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
         raise L.UclstmError("igemm_atomic(slabs=True): acc_out must be a contiguous [ksplit_used, pixels, ld] tensor")
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
     _log_shape(d)
-    _timed(kind, flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
+    _same_act_dtype([sv.t for sv in srcs] + [wp], "igemm_fwd(atomic)")
+    K = _k(wp)
+    _timed(kind, flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
 
 
@@ -654,7 +702,9 @@ def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
     flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * ((x.shape[3] if x is not None else 0) + h_prev.shape[3])
     _log_shape(d)
-    _timed("igemm_fwd_lstm", flops, lambda: L.check(L.lib.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
+    _same_act_dtype([h_prev, wp, h_out] + ([x] if x is not None else []) + ([gates_out] if gates_out is not None else []), "igemm_fwd(lstm)")
+    K = _k(wp)
+    _timed("igemm_fwd_lstm", flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
            f"M={B * H * W} N={d.N} K={d.Ktot}")
 
 
@@ -663,6 +713,8 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     """Weight-gradient GEMM; returns the f32 panel gradient as pixel-range slabs [splits, N, Ktot] (the unpack adds them).
     Operands beyond the single-launch byte range are processed as image ranges, each range contributing its own slabs."""
     dev = srcs[0].t.device
+    _same_act_dtype([sv.t for sv in srcs] + [sg[0] for sg in dy_segs], "igemm_wgrad")
+    K = _k(srcs[0].t)
     per_img = max([_bytes_per_img(sv.t) for sv in srcs] + [_bytes_per_img(sg[0]) for sg in dy_segs])
     chunks = _img_chunks(n_img, 1, per_img, "igemm_wgrad")
     descs = []
@@ -693,16 +745,16 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
         d.dwp = dwp[at].data_ptr()
         at += d.splits
         flops = 2.0 * d.n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
-        _timed("igemm_wgrad", flops, lambda d=d: L.check(L.lib.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
+        _timed("igemm_wgrad", flops, lambda d=d: L.check(K.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
                f"M={d.n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
     return dwp
 
 
 def colsum(a: torch.Tensor) -> torch.Tensor:
-    _dev(a, BF16, "colsum input")
+    _dev(a, ACT, "colsum input")
     Cp = a.shape[-1]
     out = torch.zeros((Cp,), dtype=F32, device=a.device)
-    L.check(L.lib.uclstm_colsum(_p(a), _p(out), a.numel() // Cp, Cp, _stream()), "colsum")
+    L.check(_k(a).uclstm_colsum(_p(a), _p(out), a.numel() // Cp, Cp, _stream()), "colsum")
     return out
 
 
@@ -716,8 +768,8 @@ class ToNHWC(torch.autograd.Function):
     def forward(ctx, x):
         _dev(x, F32, "input")
         N, Cc, H, W = x.shape
-        out = torch.empty((N, H, W, cpad(Cc)), dtype=BF16, device=x.device)
-        L.check(L.lib.uclstm_nchw_to_nhwc(_p(x), _p(out), N, Cc, cpad(Cc), H, W, N, 0, Cc * H * W, _stream()), "nchw_to_nhwc")
+        out = torch.empty((N, H, W, cpad(Cc)), dtype=_COMPUTE_DTYPE, device=x.device)
+        L.check(_k(out).uclstm_nchw_to_nhwc(_p(x), _p(out), N, Cc, cpad(Cc), H, W, N, 0, Cc * H * W, _stream()), "nchw_to_nhwc")
         ctx.C = Cc
         return out
 
@@ -726,7 +778,7 @@ class ToNHWC(torch.autograd.Function):
         g = g.contiguous()
         N, H, W, Cp = g.shape
         out = torch.empty((N, ctx.C, H, W), dtype=F32, device=g.device)
-        L.check(L.lib.uclstm_nhwc_to_nchw(_p(g), _p(out), N, ctx.C, Cp, H, W, _stream()), "nhwc_to_nchw")
+        L.check(_k(g).uclstm_nhwc_to_nchw(_p(g), _p(out), N, ctx.C, Cp, H, W, _stream()), "nhwc_to_nchw")
         return out
 
 
@@ -735,19 +787,20 @@ class FromNHWC(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, Cc):
-        _dev(a, BF16, "activation")
+        _dev(a, ACT, "activation")
         N, H, W, Cp = a.shape
         out = torch.empty((N, Cc, H, W), dtype=F32, device=a.device)
-        L.check(L.lib.uclstm_nhwc_to_nchw(_p(a), _p(out), N, Cc, Cp, H, W, _stream()), "nhwc_to_nchw")
+        L.check(_k(a).uclstm_nhwc_to_nchw(_p(a), _p(out), N, Cc, Cp, H, W, _stream()), "nhwc_to_nchw")
         ctx.Cp = Cp
+        ctx.act_dtype = a.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         N, Cc, H, W = g.shape
-        out = torch.empty((N, H, W, ctx.Cp), dtype=BF16, device=g.device)
-        L.check(L.lib.uclstm_nchw_grad_to_nhwc(_p(g), _p(out), N, Cc, ctx.Cp, H, W, _stream()), "nchw_grad_to_nhwc")
+        out = torch.empty((N, H, W, ctx.Cp), dtype=ctx.act_dtype, device=g.device)
+        L.check(_k(out).uclstm_nchw_grad_to_nhwc(_p(g), _p(out), N, Cc, ctx.Cp, H, W, _stream()), "nchw_grad_to_nhwc")
         return out, None
 
 
@@ -805,8 +858,8 @@ def im2col_first(x: torch.Tensor, time_major: bool) -> torch.Tensor:
         n_img, Cc, H, W = x.shape
         inner, inner_stride, outer_stride = n_img, 0, Cc * H * W
     Kp = cpad(9 * Cc)
-    out = torch.empty((n_img, H, W, Kp), dtype=BF16, device=x.device)
-    L.check(L.lib.uclstm_im2col3x3_first(_p(x), _p(out), n_img, Cc, Kp, H, W, inner, inner_stride, outer_stride, _stream()),
+    out = torch.empty((n_img, H, W, Kp), dtype=_COMPUTE_DTYPE, device=x.device)
+    L.check(_k(out).uclstm_im2col3x3_first(_p(x), _p(out), n_img, Cc, Kp, H, W, inner, inner_stride, outer_stride, _stream()),
             "im2col3x3_first")
     return out
 
@@ -826,7 +879,7 @@ class ConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, gamma, beta, running_mean, running_var, c_valid, off, groups, training, momentum, eps,
                 im2col):
-        _dev(x0, BF16, "x0")
+        _dev(x0, ACT, "x0")
         Co, Ci_total = weight.shape[0], weight.shape[1]
         Cop = cpad(Co)
         n_img, H, W, _ = x0.shape
@@ -840,9 +893,10 @@ class ConvBNReLU(torch.autograd.Function):
             pd = conv_pack_desc(Co, Ci_total, list(c_valid), c_pad)
             srcs = [SrcView(x0)] + ([SrcView(x1, off[0], off[1])] if x1 is not None else [])
             ktap, pad = 3, 1
-        wp = pack_weights(pd, weight)
+        wp = pack_weights(pd, weight, 0, x0.dtype)
         bp = pack_bias(pd, bias) if bias is not None else None
-        out = torch.empty((n_img, H, W, Cop), dtype=BF16, device=dev)
+        out = torch.empty((n_img, H, W, Cop), dtype=x0.dtype, device=dev)
+        K = _k(x0)
         need_bw = any(ctx.needs_input_grad)
         if training:
             ppg = (n_img // groups) * H * W
@@ -855,7 +909,7 @@ class ConvBNReLU(torch.autograd.Function):
                                              _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
                                              _stream()), "bn_finalize")
             a = torch.empty_like(z)
-            L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
+            L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
                     "bn_apply_relu")
             ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
             note_use(weight, gamma, beta, bias)
@@ -869,7 +923,7 @@ class ConvBNReLU(torch.autograd.Function):
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                              momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _stream()), "bn_finalize(eval)")
             a = torch.empty_like(z)
-            L.check(L.lib.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, n_img * H * W, Cop, _stream()),
+            L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, n_img * H * W, Cop, _stream()),
                     "bn_apply_relu")
             ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
             note_use(weight, gamma, beta, bias)
@@ -894,13 +948,14 @@ class ConvBNReLU(torch.autograd.Function):
         pixels, ppg = n_img * H * W, (n_img // groups) * H * W
         sums = torch.empty((groups, Cop, 2), dtype=F32, device=dev)
         partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
-        L.check(L.lib.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
+        K = _k(z)
+        L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
                                            _stream()), "bn_bwd_reduce")
         dz = torch.empty_like(z)
         # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
         # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
         sums_dz = sums if training else torch.zeros_like(sums)
-        L.check(L.lib.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz), pixels, ppg,
+        L.check(K.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz), pixels, ppg,
                                           Cop, _stream()), "bn_bwd_apply")
         # training: the conv bias feeds BatchNorm, which removes any per-channel constant -- its gradient is analytically 0.
         # With frozen statistics it is the column sum of dz.
@@ -942,12 +997,12 @@ class ConvBNReLU(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] and not im2col:
             dd = conv_dgrad_pack_desc(Co, Ci_total, c_valid[0])
-            wd = pack_weights(dd, weight, 0)
+            wd = pack_weights(dd, weight, 0, dz.dtype)
             dx0 = torch.empty_like(x0)
             igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx0, 0, dd.N, 0, 1, 0, 0)], ktap=3, pad=1)
         if x1 is not None and ctx.needs_input_grad[1]:
             dd = conv_dgrad_pack_desc(Co, Ci_total, c_valid[1])
-            wd = pack_weights(dd, weight, c_valid[0] * 9)
+            wd = pack_weights(dd, weight, c_valid[0] * 9, dz.dtype)
             dx1 = torch.empty_like(x1)
             igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx1, 0, dd.N, 0, 1, -off[0], -off[1])], ktap=3, pad=1)
         return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
@@ -959,10 +1014,10 @@ class ConvBNReLU(torch.autograd.Function):
 class MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a):
-        _dev(a, BF16, "activation")
+        _dev(a, ACT, "activation")
         N, H, W, Cp = a.shape
-        p = torch.empty((N, H // 2, W // 2, Cp), dtype=BF16, device=a.device)
-        L.check(L.lib.uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
+        p = torch.empty((N, H // 2, W // 2, Cp), dtype=a.dtype, device=a.device)
+        L.check(_k(a).uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
         ctx.save_for_backward(a)
         return p
 
@@ -972,7 +1027,7 @@ class MaxPool2(torch.autograd.Function):
         dp = dp.contiguous()
         N, H, W, Cp = a.shape
         da = torch.zeros_like(a) if (H % 2 or W % 2) else torch.empty_like(a)
-        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), None, _p(da), N, H, W, Cp, _stream()), "maxpool2_bwd")
+        L.check(_k(a).uclstm_maxpool2_bwd(_p(a), _p(dp), None, _p(da), N, H, W, Cp, _stream()), "maxpool2_bwd")
         return da
 
 
@@ -983,10 +1038,10 @@ class MaxPool2Skip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a):
-        _dev(a, BF16, "activation")
+        _dev(a, ACT, "activation")
         N, H, W, Cp = a.shape
-        p = torch.empty((N, H // 2, W // 2, Cp), dtype=BF16, device=a.device)
-        L.check(L.lib.uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
+        p = torch.empty((N, H // 2, W // 2, Cp), dtype=a.dtype, device=a.device)
+        L.check(_k(a).uclstm_maxpool2_fwd(_p(a), _p(p), N, H, W, Cp, _stream()), "maxpool2_fwd")
         ctx.save_for_backward(a)
         return p, a.view_as(a)
 
@@ -1000,7 +1055,7 @@ class MaxPool2Skip(torch.autograd.Function):
         odd = bool(H % 2 or W % 2)
         da = torch.zeros_like(a) if odd else torch.empty_like(a)
         fused = dskip is not None and not odd
-        L.check(L.lib.uclstm_maxpool2_bwd(_p(a), _p(dp), _p(dskip.contiguous()) if fused else None, _p(da), N, H, W, Cp, _stream()),
+        L.check(_k(a).uclstm_maxpool2_bwd(_p(a), _p(dp), _p(dskip.contiguous()) if fused else None, _p(da), N, H, W, Cp, _stream()),
                 "maxpool2_bwd")
         if dskip is not None and not fused:
             da = da + dskip
@@ -1013,14 +1068,14 @@ class MaxPool2Skip(torch.autograd.Function):
 class ConvT2x2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        _dev(x, BF16, "activation")
+        _dev(x, ACT, "activation")
         Ci, Co = weight.shape[0], weight.shape[1]
         Cop = cpad(Co)
         N, h, w, _ = x.shape
         pd = convt_pack_desc(Ci, Co)
-        wp = pack_weights(pd, weight)
+        wp = pack_weights(pd, weight, 0, x.dtype)
         bp = pack_bias(pd, bias) if bias is not None else None
-        u = torch.empty((N, 2 * h, 2 * w, Cop), dtype=BF16, device=x.device)
+        u = torch.empty((N, 2 * h, 2 * w, Cop), dtype=x.dtype, device=x.device)
         segs = [(u, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
         igemm_store([SrcView(x)], wp, (h, w), N, segs, ktap=1, pad=0, bias=bp)
         ctx.save_for_backward(x, weight)
@@ -1043,7 +1098,7 @@ class ConvT2x2(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dd = convt_dgrad_pack_desc(Ci, Co)
-            wd = pack_weights(dd, weight)
+            wd = pack_weights(dd, weight, 0, du.dtype)
             dx = torch.empty_like(x)
             igemm_store([SrcView(du)], wd, (h, w), N, [(dx, 0, dd.N, 0, 1, 0, 0)], ktap=2, scale=2, pad=0)
         return dx, dweight, dbias
@@ -1057,11 +1112,11 @@ class OutConv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, weight, bias):
-        _dev(a, BF16, "activation")
+        _dev(a, ACT, "activation")
         N, H, W, Cp = a.shape
         Co, Ci = weight.shape[0], weight.shape[1]
         y = torch.empty((N, Co, H, W), dtype=F32, device=a.device)
-        L.check(L.lib.uclstm_outconv_fwd(_p(a), _p(weight), _p(bias), _p(y), N, H * W, Cp, Ci, Co, _stream()), "outconv_fwd")
+        L.check(_k(a).uclstm_outconv_fwd(_p(a), _p(weight), _p(bias), _p(y), N, H * W, Cp, Ci, Co, _stream()), "outconv_fwd")
         ctx.save_for_backward(a, weight)
         ctx.has_bias = bias is not None
         return y
@@ -1075,7 +1130,7 @@ class OutConv1x1(torch.autograd.Function):
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         dw = torch.zeros((Co, Ci), dtype=F32, device=a.device)
         db = torch.zeros((Co,), dtype=F32, device=a.device)
-        L.check(L.lib.uclstm_outconv_bwd(_p(a), _p(weight), _p(dy), _p(da), _p(dw), _p(db), N, H * W, Cp, Ci, Co, _stream()),
+        L.check(_k(a).uclstm_outconv_bwd(_p(a), _p(weight), _p(dy), _p(da), _p(dw), _p(db), N, H * W, Cp, Ci, Co, _stream()),
                 "outconv_bwd")
         return da, dw.view_as(weight), (db if ctx.has_bias else None)
 
@@ -1097,14 +1152,16 @@ class ConvLSTMSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_all, h0, c0, weight, bias, Hd, Cx, need_grad):
         ctx.set_materialize_grads(False)
-        _dev(x_all, BF16, "x_all")
+        _dev(x_all, ACT, "x_all")
+        adt = x_all.dtype
+        K = _k(x_all)
         T, B, H, W, Cxp = x_all.shape
         Hdp = cpad(Hd)
         dev = x_all.device
         ks = weight.shape[-1]
         pd = lstm_pack_desc(Hd, Cx, ks)
         bp = pack_bias(pd, bias) if bias is not None else None
-        h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=BF16, device=dev)
+        h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=adt, device=dev)
         c_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=F32, device=dev)
         if h0 is None:
             h_hist[0].zero_()
@@ -1112,7 +1169,7 @@ class ConvLSTMSeq(torch.autograd.Function):
             h_hist[0].copy_(h0)
         if c0 is not None:
             c_hist[0].copy_(c0)
-        gates = torch.empty((T, B, H, W, 4, Hdp), dtype=BF16, device=dev) if need_grad else None
+        gates = torch.empty((T, B, H, W, 4, Hdp), dtype=adt, device=dev) if need_grad else None
         pixels = B * H * W
         # Per-step GEMM M = B*H*W.  When its tile grid cannot fill the chip (bottleneck LSTM: M = 512), run the gate
         # convolution as split-K partial tiles in f32 slabs and apply the cell update in a point-wise kernel; otherwise one
@@ -1121,8 +1178,8 @@ class ConvLSTMSeq(torch.autograd.Function):
         if hoist:
             # W_x * x_t for ALL timesteps as one GEMM over T*B*H*W pixels (f32 pre-activations in panel-row order); the
             # recurrence then multiplies only by W_h: K and the weight bytes re-read per step halve
-            wx = pack_weights(lstm_half_pack_desc(Hd, Cx, "x", ks), weight)
-            wp = pack_weights(lstm_half_pack_desc(Hd, Cx, "h", ks), weight)
+            wx = pack_weights(lstm_half_pack_desc(Hd, Cx, "x", ks), weight, 0, adt)
+            wp = pack_weights(lstm_half_pack_desc(Hd, Cx, "h", ks), weight, 0, adt)
             N = wp.shape[0]
             pre_x = torch.empty((1, T * pixels, N), dtype=F32, device=dev)
             for i0, i1 in _img_chunks(T * B, 1, max(_bytes_per_img(x_all[0]), H * W * N * 4), "convlstm x half"):
@@ -1130,7 +1187,7 @@ class ConvLSTMSeq(torch.autograd.Function):
                              pre_x[:, i0 * H * W:i1 * H * W], 1, ktap=ks, pad=ks // 2, slabs=True, kind="igemm_fwd_xhoist")
             pre_x = pre_x.view(T, pixels, N)
         else:
-            wp = pack_weights(pd, weight)
+            wp = pack_weights(pd, weight, 0, adt)
         ksplit = split_k_factor(pixels, wp.shape[0], wp.shape[1] // 64)
         # one f32 slab per K range (plain stores; the point-wise kernel adds them): no atomics, nothing to zero
         nsl = ksplit_used(wp.shape[1], ksplit) if ksplit > 1 else 0
@@ -1142,11 +1199,11 @@ class ConvLSTMSeq(torch.autograd.Function):
             srcs = ([] if hoist else [SrcView(x_all[t])]) + [SrcView(h_hist[t])]
             if hoist and t == 0 and h0 is None:
                 # zero initial state (train/unet.py:23-25): W_h * 0 = 0, the step is the point-wise update of W_x * x_0
-                L.check(L.lib.uclstm_lstm_fwd_pointwise(None, 0, 0, 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[1]), _p(h_hist[1]),
+                L.check(K.uclstm_lstm_fwd_pointwise(None, 0, 0, 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[1]), _p(h_hist[1]),
                                                         _p(g_t), pixels, Hdp, _stream()), "lstm_fwd_pointwise")
             elif ksplit > 1:
                 igemm_atomic(srcs, wp, (H, W), B, pre, ksplit, ktap=ks, pad=ks // 2, slabs=True)
-                L.check(L.lib.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[t + 1]),
+                L.check(K.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[t + 1]),
                                                         _p(h_hist[t + 1]), _p(g_t), pixels, Hdp, _stream()), "lstm_fwd_pointwise")
             else:
                 igemm_lstm(None if hoist else x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks, pre_add=px_t)
@@ -1165,29 +1222,30 @@ class ConvLSTMSeq(torch.autograd.Function):
         dev = x_all.device
         pixels = B * H * W
         dh_all = None if dh_all is None else dh_all.contiguous()
-        dgates = torch.empty((T, B, H, W, 4 * Hdp), dtype=BF16, device=dev)
+        adt = x_all.dtype
+        K = _k(x_all)
+        dgates = torch.empty((T, B, H, W, 4 * Hdp), dtype=adt, device=dev)
         dc = torch.empty((B, H, W, Hdp), dtype=F32, device=dev)
         dc_zero = dc_T is None
         if not dc_zero:
             dc.copy_(dc_T)
         ddh = lstm_dgrad_pack_desc(Hd, Cx, Hd, ks)
-        wd_h = pack_weights(ddh, weight, Cx * ks * ks)
+        wd_h = pack_weights(ddh, weight, Cx * ks * ks, adt)
         dh_rec = None
         # recurrent gradient dh_{t-1} = W_h^T (*) dgates_t: M = B*H*W pixels, N = Hd, K = 9*4*Hd.  Small M -> split-K with
         # f32 atomics into dh (read back as f32 by the next step's point-wise kernel); else a plain bf16 store.
         ksplit = split_k_factor(pixels, ddh.N, ddh.Ktot // 64)
-        rec_dtype = F32 if ksplit > 1 else BF16
         # split-K: one f32 slab per K range, plain stores; the point-wise kernel of the next (earlier) timestep adds them.
         # Two buffers alternate so that step t's GEMM never writes what step t+1's point-wise kernel still reads.
         nsl = ksplit_used(ddh.Ktot, ksplit) if ksplit > 1 else 1
         if ksplit > 1:
             buf = [torch.empty((nsl, B, H, W, Hdp), dtype=F32, device=dev) for _ in range(2)]
         else:
-            buf = [torch.empty((B, H, W, Hdp), dtype=BF16, device=dev) for _ in range(2)]
+            buf = [torch.empty((B, H, W, Hdp), dtype=adt, device=dev) for _ in range(2)]
         need_h0 = ctx.needs_input_grad[1]
         for t in range(T - 1, -1, -1):
             c_prev = c_hist[t] if (has_c0 or t > 0) else None
-            L.check(L.lib.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
+            L.check(K.uclstm_lstm_bwd_pointwise(_p(gates[t]), _p(c_prev), _p(c_hist[t + 1]),
                                                     _p(dh_all[t]) if dh_all is not None else None, _p(dh_rec),
                                                     1 if ksplit > 1 else 0, nsl, pixels * Hdp, _p(dc),
                                                     int(dc_zero), _p(dgates[t]), pixels, Hdp, _stream()), "lstm_bwd_pointwise")
@@ -1213,11 +1271,11 @@ class ConvLSTMSeq(torch.autograd.Function):
         dx_all = None
         if ctx.needs_input_grad[0]:
             ddx = lstm_dgrad_pack_desc(Hd, Cx, Cx, ks)
-            wd_x = pack_weights(ddx, weight, 0)
+            wd_x = pack_weights(ddx, weight, 0, adt)
             dx_all = torch.empty_like(x_all)
             igemm_store([SrcView(dg_flat)], wd_x, (H, W), T * B, [(dx_all.view(T * B, H, W, Cxp), 0, ddx.N, 0, 1, 0, 0)], ktap=ks,
                         pad=ks // 2)
-        dh0 = (dh_rec if dh_rec.dtype == BF16 else dh_rec.sum(dim=0).to(BF16)) if need_h0 else None
+        dh0 = (dh_rec if dh_rec.dtype == adt else dh_rec.sum(dim=0).to(adt)) if need_h0 else None
         dc0 = dc if (has_c0 and ctx.needs_input_grad[2]) else None
         return dx_all, dh0, dc0, dweight, dbias, None, None, None
 

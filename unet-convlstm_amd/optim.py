@@ -55,7 +55,8 @@ class FusedAdamW(torch.optim.Optimizer):
     flat buffer (``set_to_none`` is accepted and ignored).
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm: Optional[float] = None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm: Optional[float] = None,
+                 loss_scale: Optional[float] = None, scale_growth: float = 2.0, scale_backoff: float = 0.5, scale_interval: int = 2000):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
@@ -68,6 +69,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.flat.flat_p.device)
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
+        # fp16 compute (ops.compute_dtype(torch.float16)): dynamic loss scaling, all on the device.  ``scale_state`` =
+        # [scale, growth tracker, successful steps]; the training step multiplies the loss by scale_state[0] before backward.
+        self.scale_state = None
+        self._scale_cfg = (float(scale_growth), float(scale_backoff), int(scale_interval))
+        if loss_scale is not None:
+            self.scale_state = torch.tensor([float(loss_scale), 0.0, 0.0], dtype=torch.float32, device=self.flat.flat_p.device)
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 - signature parity with torch
         self.flat.zero_grad()
@@ -77,7 +84,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()
         sd["fused"] = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "step": int(self.step_count),
-                       "numel": int(self.flat.numel)}
+                       "numel": int(self.flat.numel),
+                       "scale_state": None if self.scale_state is None else self.scale_state.detach().clone()}
         return sd
 
     def load_state_dict(self, state_dict) -> None:
@@ -90,11 +98,18 @@ class FusedAdamW(torch.optim.Optimizer):
         self.m.copy_(fused["exp_avg"])
         self.v.copy_(fused["exp_avg_sq"])
         self.step_count = int(fused["step"])
+        if fused.get("scale_state") is not None and self.scale_state is not None:
+            self.scale_state.copy_(fused["scale_state"])
 
     @torch.no_grad()
     def grad_norm(self) -> torch.Tensor:
-        """Global L2 norm of the last clipped step's gradients (device scalar, f64)."""
-        return self.sumsq.sqrt()
+        """Global L2 norm of the last step's (unscaled) gradients (device scalar, f64)."""
+        n = self.sumsq.sqrt()
+        return n if self.scale_state is None else n / self._last_scale.double()
+
+    def scale_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """The tensor to call ``backward()`` on: ``loss`` itself, or ``loss * scale`` with fp16 loss scaling."""
+        return loss if self.scale_state is None else loss * self.scale_state[0]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -105,6 +120,21 @@ class FusedAdamW(torch.optim.Optimizer):
         f = self.flat
         f.attach_grads()
         self.step_count += 1
+        if self.scale_state is not None:
+            self.sumsq.zero_()
+            self._last_scale = self.scale_state[0].clone()
+            L.check(L.lib.uclstm_sumsq(C.c_void_p(f.flat_g.data_ptr()), f.numel, C.c_void_p(self.sumsq.data_ptr()), _stream()), "sumsq")
+            L.check(L.lib.uclstm_adamw_step_scaled(C.c_void_p(f.flat_p.data_ptr()), C.c_void_p(self.m.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                                   C.c_void_p(f.flat_g.data_ptr()), f.numel, C.c_void_p(self.sumsq.data_ptr()),
+                                                   float(self.max_grad_norm or 0.0), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                                   float(g["eps"]), float(g["weight_decay"]), C.c_void_p(self.scale_state.data_ptr()), _stream()),
+                    "adamw_step_scaled")
+            gr, bo, it = self._scale_cfg
+            L.check(L.lib.uclstm_loss_scale_update(C.c_void_p(self.scale_state.data_ptr()), C.c_void_p(self.sumsq.data_ptr()), gr, bo, it,
+                                                   _stream()), "loss_scale_update")
+            from . import ops
+            ops.weights_changed()
+            return None
         sq = None
         if self.max_grad_norm is not None:
             self.sumsq.zero_()

@@ -57,7 +57,7 @@ class StreamingPredictor:
         c = m.base_ch
 
         def z(ch, h, w, n_layers):
-            return [(torch.zeros((B, h, w, ops.cpad(ch)), dtype=torch.bfloat16, device=dev),
+            return [(torch.zeros((B, h, w, ops.cpad(ch)), dtype=ops.get_compute_dtype(), device=dev),
                      torch.zeros((B, h, w, ops.cpad(ch)), dtype=torch.float32, device=dev)) for _ in range(n_layers)]
         st = {"temporal": z(c * 16, H // 16, W // 16, len(m.temporal.layers))}
         if m.use_skip_lstm:
