@@ -57,7 +57,8 @@ def test_double_conv_block_fp16_is_bit_exact_against_the_fp16_storage_oracle():
     assert rel_l2(xd.grad.cpu(), xr.grad) <= 1e-2
     for k, p in dc.named_parameters():
         r = leaves["dc." + k].grad
-        if float(r.abs().max()) < 1e-4:
+        if k in ("net.0.bias", "net.3.bias"):          # conv bias in front of BatchNorm: analytically zero, exact zeros here
+            assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) < 2e-3
             continue
         assert rel_l2(p.grad.cpu(), r) <= 1e-2, k
     torch.testing.assert_close(dc.net[1].running_mean.cpu(), buf["dc.net.1.running_mean"], rtol=2e-3, atol=2e-4)
