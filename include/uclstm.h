@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 7
+#define UCLSTM_ABI_VERSION 8
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -276,6 +276,20 @@ int32_t uclstm_outconv_fwd(const void* a, const float* w, const float* b, float*
 int32_t uclstm_outconv_bwd(const void* a, const float* w, const float* dy, void* da, float* dw, float* db,
                            int64_t n_img, int32_t HW, int32_t Cp, int32_t C, int32_t Co, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* SpatialAttention (train/unet.py:113-125): mean & max over channels -> k x k conv (2 -> 1, no bias) -> sigmoid -> scale */
+/* ------------------------------------------------------------------------------------ */
+/* x, out bf16 [n_img][H][W][Cp] (C valid channels); w f32 [2][k][k] (the reference's [1,2,k,k] conv weight, k odd <= 15).
+ * Outputs kept for the backward pass: att f32 [pixels] (the sigmoid map), desc f32 [pixels][2] (mean, max), argmax int32
+ * [pixels] (first channel attaining the max: where torch.max routes the gradient). */
+int32_t uclstm_attention_fwd(const void* x, const float* w, void* out, float* att, float* desc, int32_t* argmax, int32_t n_img,
+                             int32_t H, int32_t W, int32_t Cp, int32_t C, int32_t k, void* stream);
+/* dx bf16 = gradient w.r.t. x; dw f32 [2][k][k] = (dw_accumulate ? dw : 0) + weight gradient (deterministic block reductions);
+ * scratch: f32 [3 * pixels + 2] work space. */
+int32_t uclstm_attention_bwd(const void* x, const void* dout, const float* w, const float* att, const float* desc,
+                             const int32_t* argmax, void* dx, float* dw, int32_t dw_accumulate, float* scratch, int32_t n_img,
+                             int32_t H, int32_t W, int32_t Cp, int32_t C, int32_t k, void* stream);
+
 /* column sums of a bf16 [pixels][Cp] tensor into f32 [Cp] (bias gradients); out must be zeroed. */
 int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int32_t Cp, void* stream);
 
@@ -358,6 +372,8 @@ UCLSTM_F16_TWIN(uclstm_im2col3x3_first)
 UCLSTM_F16_TWIN(uclstm_outconv_fwd)
 UCLSTM_F16_TWIN(uclstm_outconv_bwd)
 UCLSTM_F16_TWIN(uclstm_colsum)
+UCLSTM_F16_TWIN(uclstm_attention_fwd)
+UCLSTM_F16_TWIN(uclstm_attention_bwd)
 
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);

@@ -201,7 +201,7 @@ def spatial_attention(x: Tensor, p: Params, prefix: str) -> Tensor:
     w = p[f"{prefix}.conv.weight"]
     desc = torch.cat((x.mean(dim=1, keepdim=True), x.max(dim=1, keepdim=True).values), dim=1)
     att = torch.sigmoid(F.conv2d(desc, w, None, padding=w.shape[-1] // 2))
-    return x * att
+    return _q(x * att)          # the HIP path stores the scaled map in 16 bits (descriptor, conv and sigmoid stay f32)
 
 
 # ---------------------------------------------------------------------------

@@ -760,3 +760,40 @@ def test_maxpool_skip_backward_equals_pool_backward_plus_skip_gradient(N, H, W, 
     a4 = a.clone().requires_grad_(True)
     ops.MaxPool2.apply(a4).backward(gp)
     assert torch.equal(a3.grad, a4.grad)
+
+
+# ---------------------------------------------------------------------------------------------
+# SpatialAttention (train/unet.py:113-125) on the HIP path
+# ---------------------------------------------------------------------------------------------
+def test_spatial_attention_golden_forward():
+    g = sub(load_golden("blocks"), "att/")
+    sa = U.SpatialAttention().to(DEV)
+    sa.load_state_dict(sub(g, "p/"))
+    with torch.no_grad():
+        y = sa(g["x"].to(DEV))
+    check_bf16(y.cpu(), g["y"], "SpatialAttention vs reference", l2=6e-3, mx=3e-2)
+
+
+@pytest.mark.parametrize("N,C,H,W,k,dtype", [(2, 16, 6, 6, 7, "bf16"), (3, 21, 5, 9, 7, "bf16"), (2, 136, 4, 4, 3, "bf16"), (2, 40, 8, 8, 7, "f16")])
+def test_spatial_attention_forward_backward_vs_oracle(N, C, H, W, k, dtype):
+    """Forward and both gradients (input, 2 -> 1 conv weight) against the oracle's autograd on the same 16-bit-rounded input;
+    channel counts that are not multiples of 8, non-square maps, the max-channel tie rule (first maximum)."""
+    torch.manual_seed(55)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    sa = U.SpatialAttention(k).to(DEV)
+    x = torch.randn(N, C, H, W).to(dt).float()
+    x[0, 3, 1, 1] = x[0, :, 1, 1].max() + 1.0
+    x[0, 5, 1, 1] = x[0, 3, 1, 1]                      # a tie: the gradient of max goes to the FIRST maximal channel (3)
+    go = torch.randn(N, C, H, W).to(dt).float()
+    with ops.compute_dtype(dt):
+        xd = x.to(DEV).requires_grad_(True)
+        y = sa(xd)
+    (y * go.to(DEV)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    wr = sa.conv.weight.detach().cpu().clone().requires_grad_(True)
+    yr = O.spatial_attention(xr, {"a.conv.weight": wr}, "a")
+    (yr * go).sum().backward()
+    tol = 4e-3 if dtype == "bf16" else 6e-4
+    e_y, e_x, e_w = rel_l2(y.detach().cpu(), yr.detach()), rel_l2(xd.grad.cpu(), xr.grad), rel_l2(sa.conv.weight.grad.cpu(), wr.grad)
+    print(f"[parity] SpatialAttention {dtype} C={C} {H}x{W} k={k}: out {e_y:.2e}, dx {e_x:.2e}, dw {e_w:.2e}")
+    assert e_y <= tol and e_x <= 2 * tol and e_w <= 2 * tol

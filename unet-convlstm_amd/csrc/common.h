@@ -26,6 +26,8 @@
 #define uclstm_outconv_fwd uclstm_outconv_fwd_f16
 #define uclstm_outconv_bwd uclstm_outconv_bwd_f16
 #define uclstm_colsum uclstm_colsum_f16
+#define uclstm_attention_fwd uclstm_attention_fwd_f16
+#define uclstm_attention_bwd uclstm_attention_bwd_f16
 #endif
 #include "../../include/uclstm.h"
 

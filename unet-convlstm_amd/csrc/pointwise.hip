@@ -4,6 +4,7 @@
 // over pixels keep a fixed channel chunk per thread, reduce across the block in LDS and finish with
 // one f32 atomic per (block, channel).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -787,6 +788,173 @@ __global__ void colsum_kernel(const uint4* __restrict__ a, float* __restrict__ o
 
 bool aligned16(const void* p) { return p && ((uintptr_t)p % 16) == 0; }
 
+
+// ---------------------------------------------------------------------------------------------
+// SpatialAttention (train/unet.py:113-125): channel mean & max -> k x k conv (2 -> 1, no bias) -> sigmoid -> scale
+// ---------------------------------------------------------------------------------------------
+// Small maps (the bottleneck: 4x4 .. 32x32 pixels, C = 16 * base_ch channels), HBM-bound on x; five kernels forward + backward
+// per call, each one pass.  desc[pixel] = (mean_c x, max_c x) in f32, arg[pixel] = first channel that attains the max.
+__global__ __launch_bounds__(256) void attn_desc_kernel(const uint4* __restrict__ x, float* __restrict__ desc, int* __restrict__ arg,
+                                                        int64_t pixels, int Cp, int C) {
+    const int lane = threadIdx.x & 63;
+    const int cpc = Cp >> 3;
+    for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < pixels; pix += (int64_t)gridDim.x * 4) {
+        float sum = 0.f, mx = -INFINITY;
+        int am = 0x7fffffff;
+        for (int ch = lane; ch < cpc; ch += 64) {
+            float f[8];
+            unpack8(x[pix * cpc + ch], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = ch * 8 + i;
+                if (c < C) {
+                    sum += f[i];
+                    if (f[i] > mx) { mx = f[i]; am = c; }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o, 64);
+            const float omx = __shfl_xor(mx, o, 64);
+            const int oam = __shfl_xor(am, o, 64);
+            if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+        }
+        if (lane == 0) {
+            desc[pix * 2] = sum / (float)C;
+            desc[pix * 2 + 1] = mx;
+            arg[pix] = am;
+        }
+    }
+}
+
+// att[p] = sigmoid(sum_{j,ky,kx} w[j][ky][kx] * desc[p + (ky - k/2, kx - k/2)][j])   (zero padding)
+__global__ void attn_map_kernel(const float* __restrict__ desc, const float* __restrict__ w, float* __restrict__ att, int64_t pixels, int H,
+                                int W, int k) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= pixels) return;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const int64_t img0 = pix - (int64_t)yy * W - xx;
+    const int r = k / 2;
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+        const int y2 = yy + ky - r;
+        if ((unsigned)y2 >= (unsigned)H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int x2 = xx + kx - r;
+            if ((unsigned)x2 >= (unsigned)W) continue;
+            const float2 dsc = *(const float2*)(desc + (img0 + (int64_t)y2 * W + x2) * 2);
+            acc += w[ky * k + kx] * dsc.x + w[k * k + ky * k + kx] * dsc.y;
+        }
+    }
+    att[pix] = 1.f / (1.f + __expf(-acc));
+}
+
+// out = x * att[pixel]
+__global__ void attn_scale_kernel(const uint4* __restrict__ x, const float* __restrict__ att, uint4* __restrict__ out, int64_t chunks,
+                                  FastDiv dcpc) {
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dcpc);
+        const float a = att[pix];
+        float f[8];
+        unpack8(x[idx], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] *= a;
+        out[idx] = pack8(f);
+    }
+}
+
+// dpre[p] = (sum_c dout[p][c] * x[p][c]) * att (1 - att)
+__global__ __launch_bounds__(256) void attn_bwd_dpre_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dout,
+                                                            const float* __restrict__ att, float* __restrict__ dpre, int64_t pixels,
+                                                            int Cp) {
+    const int lane = threadIdx.x & 63;
+    const int cpc = Cp >> 3;
+    for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < pixels; pix += (int64_t)gridDim.x * 4) {
+        float acc = 0.f;
+        for (int ch = lane; ch < cpc; ch += 64) {
+            float a[8], b[8];
+            unpack8(x[pix * cpc + ch], a);
+            unpack8(dout[pix * cpc + ch], b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += a[i] * b[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            const float a = att[pix];
+            dpre[pix] = acc * a * (1.f - a);
+        }
+    }
+}
+
+// ddesc[q][j] = sum_{ky,kx} w[j][ky][kx] * dpre[q - (ky - r, kx - r)]  (transposed convolution of the 2 -> 1 conv)
+__global__ void attn_bwd_ddesc_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ ddesc,
+                                      int64_t pixels, int H, int W, int k) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= pixels) return;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const int64_t img0 = pix - (int64_t)yy * W - xx;
+    const int r = k / 2;
+    float d0 = 0.f, d1 = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+        const int y2 = yy - (ky - r);
+        if ((unsigned)y2 >= (unsigned)H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int x2 = xx - (kx - r);
+            if ((unsigned)x2 >= (unsigned)W) continue;
+            const float g = dpre[img0 + (int64_t)y2 * W + x2];
+            d0 += w[ky * k + kx] * g;
+            d1 += w[k * k + ky * k + kx] * g;
+        }
+    }
+    ddesc[pix * 2] = d0;
+    ddesc[pix * 2 + 1] = d1;
+}
+
+// dw[j][ky][kx] (+)= sum_p dpre[p] * desc[p + (ky - r, kx - r)][j]: one block per weight element, fixed-order block reduction
+__global__ __launch_bounds__(256) void attn_bwd_dw_kernel(const float* __restrict__ dpre, const float* __restrict__ desc, float* __restrict__ dw,
+                                                          int64_t pixels, int H, int W, int k, int accumulate) {
+    __shared__ double red[256];
+    const int e = blockIdx.x;
+    const int j = e / (k * k), ky = (e / k) % k, kx = e % k;
+    const int r = k / 2;
+    double acc = 0.0;
+    for (int64_t pix = threadIdx.x; pix < pixels; pix += 256) {
+        const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+        const int y2 = yy + ky - r, x2 = xx + kx - r;
+        if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+            acc += (double)(dpre[pix] * desc[(pix - (int64_t)yy * W - xx + (int64_t)y2 * W + x2) * 2 + j]);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[e] = (accumulate ? dw[e] : 0.f) + (float)red[0];
+}
+
+// dx[p][c] = dout[p][c] * att[p] + ddesc[p][0] / C + (c == arg[p]) * ddesc[p][1]     (c < C)
+__global__ void attn_bwd_dx_kernel(const uint4* __restrict__ dout, const float* __restrict__ att, const float* __restrict__ ddesc,
+                                   const int* __restrict__ arg, uint4* __restrict__ dx, int64_t chunks, FastDiv dcpc, int C) {
+    const float invC = 1.f / (float)C;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t pix = fdiv((uint32_t)idx, dcpc);
+        const int c0 = (int)((uint32_t)idx - pix * dcpc.d) * 8;
+        const float a = att[pix];
+        const float2 dd = *(const float2*)(ddesc + (int64_t)pix * 2);
+        const int am = arg[pix];
+        float f[8];
+        unpack8(dout[idx], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i;
+            f[i] = c < C ? f[i] * a + dd.x * invC + (c == am ? dd.y : 0.f) : 0.f;
+        }
+        dx[idx] = pack8(f);
+    }
+}
 }  // namespace
 
 // =============================================================================================
@@ -1082,5 +1250,40 @@ extern "C" int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int3
     const int64_t ppb = (pixels + nb - 1) / nb;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 8 * sizeof(float);
     UCLSTM_LAUNCH(colsum_kernel, dim3((unsigned)nb, (unsigned)ncg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)a, out, pixels, cg, Cp, ppb);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_attention_fwd(const void* x, const float* w, void* out, float* att, float* desc, int32_t* argmax, int32_t n_img,
+                                        int32_t H, int32_t W, int32_t Cp, int32_t C, int32_t k, void* stream) {
+    if (!aligned16(x) || !aligned16(out) || !w || !att || !desc || !argmax || n_img <= 0 || H <= 0 || W <= 0 || Cp <= 0 || (Cp % 8) || C <= 0 ||
+        C > Cp || k < 1 || !(k & 1) || k > 15 || ((uintptr_t)desc % 8))
+        return UCLSTM_E_BADARG;
+    const int64_t pixels = (int64_t)n_img * H * W, chunks = pixels * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    UCLSTM_LAUNCH(attn_desc_kernel, dim3((unsigned)std::min<int64_t>((pixels + 3) / 4, 4096)), dim3(256), 0, st, (const uint4*)x, desc, argmax, pixels,
+                  Cp, C);
+    UCLSTM_LAUNCH(attn_map_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, st, desc, w, att, pixels, H, W, k);
+    UCLSTM_LAUNCH(attn_scale_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, st, (const uint4*)x, att, (uint4*)out, chunks, make_fastdiv(Cp / 8));
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_attention_bwd(const void* x, const void* dout, const float* w, const float* att, const float* desc,
+                                        const int32_t* argmax, void* dx, float* dw, int32_t dw_accumulate, float* scratch, int32_t n_img,
+                                        int32_t H, int32_t W, int32_t Cp, int32_t C, int32_t k, void* stream) {
+    if (!aligned16(x) || !aligned16(dout) || !aligned16(dx) || !w || !att || !desc || !argmax || !dw || !scratch || n_img <= 0 || H <= 0 ||
+        W <= 0 || Cp <= 0 || (Cp % 8) || C <= 0 || C > Cp || k < 1 || !(k & 1) || k > 15 || ((uintptr_t)scratch % 8))
+        return UCLSTM_E_BADARG;
+    const int64_t pixels = (int64_t)n_img * H * W, chunks = pixels * (Cp / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* dpre = scratch;                     // [pixels]
+    float* ddesc = scratch + ((pixels + 1) & ~(int64_t)1);   // [pixels][2], 8-byte aligned
+    UCLSTM_LAUNCH(attn_bwd_dpre_kernel, dim3((unsigned)std::min<int64_t>((pixels + 3) / 4, 4096)), dim3(256), 0, st, (const uint4*)x,
+                  (const uint4*)dout, att, dpre, pixels, Cp);
+    UCLSTM_LAUNCH(attn_bwd_ddesc_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, st, dpre, w, ddesc, pixels, H, W, k);
+    UCLSTM_LAUNCH(attn_bwd_dw_kernel, dim3(2 * k * k), dim3(256), 0, st, dpre, desc, dw, pixels, H, W, k, dw_accumulate);
+    UCLSTM_LAUNCH(attn_bwd_dx_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, st, (const uint4*)dout, att, ddesc, argmax, (uint4*)dx, chunks,
+                  make_fastdiv(Cp / 8), C);
     return UCLSTM_OK;
 }

@@ -232,8 +232,9 @@ class OutConv(nn.Module):
 
 
 class SpatialAttention(nn.Module):
-    """Reference train/unet.py:113-125.  Off in every reference script (main.py:226); kept on stock
-    PyTorch-ROCm ops (SURVEY.md section 8a row 8'), outside the hand-written hot path."""
+    """Reference train/unet.py:113-125: channel mean & max -> k x k conv (2 -> 1, no bias) -> sigmoid -> scale, as HIP kernels
+    (``uclstm_attention_fwd/bwd``).  ``self.conv`` / ``self.sigmoid`` hold the parameters under the reference's names
+    (``attention.conv.weight``) and are never called."""
 
     def __init__(self, kernel_size=7):
         super().__init__()
@@ -241,15 +242,12 @@ class SpatialAttention(nn.Module):
         self.conv = nn.Conv2d(2, 1, kernel_size, padding=padding, bias=False)
         self.sigmoid = nn.Sigmoid()
 
-    def forward(self, x):
-        avg_out = x.mean(dim=1, keepdim=True)
-        max_out, _ = x.max(dim=1, keepdim=True)
-        attention = self.sigmoid(self.conv(torch.cat([avg_out, max_out], dim=1)))
-        return x * attention
-
     def forward_nhwc(self, a: Tensor, channels: int) -> Tensor:
-        x = ops.FromNHWC.apply(a, channels)
-        return ops.ToNHWC.apply(self.forward(x).contiguous())
+        return ops.SpatialAttn.apply(a, self.conv.weight, channels)
+
+    def forward(self, x):
+        a = self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()), x.shape[1])
+        return ops.FromNHWC.apply(a, x.shape[1])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1136,6 +1136,49 @@ class OutConv1x1(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# SpatialAttention  (train/unet.py:113-125)
+# ---------------------------------------------------------------------------------------------
+class SpatialAttn(torch.autograd.Function):
+    """x * sigmoid(conv_kxk([mean_c x, max_c x])) on NHWC 16-bit activations; ``weight`` is the reference's [1,2,k,k] f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, channels):
+        _dev(x, ACT, "activation")
+        _dev(weight, F32, "attention weight")
+        N, H, W, Cp = x.shape
+        k = weight.shape[-1]
+        dev = x.device
+        out = torch.empty_like(x)
+        att = torch.empty((N, H, W), dtype=F32, device=dev)
+        desc = torch.empty((N, H, W, 2), dtype=F32, device=dev)
+        arg = torch.empty((N, H, W), dtype=torch.int32, device=dev)
+        L.check(_k(x).uclstm_attention_fwd(_p(x), _p(weight), _p(out), _p(att), _p(desc), _p(arg), N, H, W, Cp, channels, k, _stream()),
+                "attention_fwd")
+        ctx.save_for_backward(x, weight, att, desc, arg)
+        ctx.channels = channels
+        if any(ctx.needs_input_grad):
+            note_use(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, att, desc, arg = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, Cp = x.shape
+        k = weight.shape[-1]
+        dx = torch.empty_like(x)
+        scratch = torch.empty((3 * N * H * W + 2,), dtype=F32, device=x.device)
+        g = direct_grad(weight)
+        dw = g if g is not None else torch.empty_like(weight)
+        L.check(_k(x).uclstm_attention_bwd(_p(x), _p(dout), _p(weight), _p(att), _p(desc), _p(arg), _p(dx), _p(dw), int(g is not None),
+                                           _p(scratch), N, H, W, Cp, ctx.channels, k, _stream()), "attention_bwd")
+        if g is not None:
+            grad_written(weight)
+            return dx, None, None
+        return dx, dw, None
+
+
+# ---------------------------------------------------------------------------------------------
 # ConvLSTM layer over a whole sequence  (train/unet.py:21-36 x T, :55-57)
 # ---------------------------------------------------------------------------------------------
 class ConvLSTMSeq(torch.autograd.Function):
