@@ -224,8 +224,7 @@ class OutConv(nn.Module):
         self.conv = nn.Conv2d(in_ch, out_ch, 1)
 
     def forward_nhwc(self, a: Tensor) -> Tensor:
-        w = self.conv.weight
-        return ops.OutConv1x1.apply(a, w.view(w.shape[0], w.shape[1]), self.conv.bias)
+        return ops.OutConv1x1.apply(a, self.conv.weight, self.conv.bias)      # the parameter itself ([Co, Ci, 1, 1]): its .grad is written directly
 
     def forward(self, x):
         return self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()))

@@ -750,12 +750,27 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
     return dwp
 
 
-def colsum(a: torch.Tensor) -> torch.Tensor:
+def colsum(a: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Column sums of a 16-bit [pixels, Cp] tensor.  ``into``: f32 [Cp] buffer the sums are ADDED to (e.g. an attached bias
+    gradient: saves the zero-fill, the slice copy and autograd's accumulate kernel); else a fresh zeroed vector."""
     _dev(a, ACT, "colsum input")
     Cp = a.shape[-1]
-    out = torch.zeros((Cp,), dtype=F32, device=a.device)
+    out = into if into is not None else torch.zeros((Cp,), dtype=F32, device=a.device)
     L.check(_k(a).uclstm_colsum(_p(a), _p(out), a.numel() // Cp, Cp, _stream()), "colsum")
     return out
+
+
+def bias_grad_from_colsum(a: torch.Tensor, bias: Optional[torch.Tensor], valid: int) -> Optional[torch.Tensor]:
+    """Bias gradient = column sums of ``a`` ([..., Cp], ``valid`` real channels).  When the bias owns an attached f32 gradient
+    of exactly Cp elements the kernel accumulates straight into it and ``None`` is returned for autograd."""
+    if bias is None:
+        return None
+    g = direct_grad(bias)
+    if g is not None and g.numel() == a.shape[-1] == valid:
+        colsum(a, into=g.view(-1))
+        grad_written(bias)
+        return None
+    return colsum(a)[:valid].contiguous()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1078,15 +1093,15 @@ class ConvT2x2(torch.autograd.Function):
         u = torch.empty((N, 2 * h, 2 * w, Cop), dtype=x.dtype, device=x.device)
         segs = [(u, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
         igemm_store([SrcView(x)], wp, (h, w), N, segs, ktap=1, pad=0, bias=bp)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias)
         ctx.has_bias = bias is not None
         if any(ctx.needs_input_grad):
-            note_use(weight)
+            note_use(weight, bias)
         return u
 
     @staticmethod
     def backward(ctx, du):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         du = du.contiguous()
         Ci, Co = weight.shape[0], weight.shape[1]
         Cop = cpad(Co)
@@ -1094,7 +1109,7 @@ class ConvT2x2(torch.autograd.Function):
         pd = convt_pack_desc(Ci, Co)
         segs = [(du, t * Cop, (t + 1) * Cop, 0, 2, t // 2, t % 2) for t in range(4)]
         dweight = wgrad_into_param(weight, pd, [x, du], lambda: igemm_wgrad([SrcView(x)], segs, pd.N, pd.Ktot, (h, w), N, ktap=1, pad=0))
-        dbias = colsum(du)[:Co].contiguous() if ctx.has_bias else None
+        dbias = bias_grad_from_colsum(du, bias, Co) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             dd = convt_dgrad_pack_desc(Ci, Co)
@@ -1108,7 +1123,7 @@ class ConvT2x2(torch.autograd.Function):
 # OutConv 1x1  (train/unet.py:101-107)
 # ---------------------------------------------------------------------------------------------
 class OutConv1x1(torch.autograd.Function):
-    """bf16 NHWC in, f32 NCHW out (the model's public output dtype/layout)."""
+    """16-bit NHWC in, f32 NCHW out (the model's public output dtype/layout)."""
 
     @staticmethod
     def forward(ctx, a, weight, bias):
@@ -1117,21 +1132,33 @@ class OutConv1x1(torch.autograd.Function):
         Co, Ci = weight.shape[0], weight.shape[1]
         y = torch.empty((N, Co, H, W), dtype=F32, device=a.device)
         L.check(_k(a).uclstm_outconv_fwd(_p(a), _p(weight), _p(bias), _p(y), N, H * W, Cp, Ci, Co, _stream()), "outconv_fwd")
-        ctx.save_for_backward(a, weight)
+        ctx.save_for_backward(a, weight, bias)
         ctx.has_bias = bias is not None
+        if any(ctx.needs_input_grad):
+            note_use(weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, weight = ctx.saved_tensors
+        a, weight, bias = ctx.saved_tensors
         dy = dy.contiguous().float()
         N, H, W, Cp = a.shape
         Co, Ci = weight.shape[0], weight.shape[1]
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros((Co, Ci), dtype=F32, device=a.device)
-        db = torch.zeros((Co,), dtype=F32, device=a.device)
+        # the kernel ADDS its block sums into dw / db: with attached f32 gradients it adds straight into them (no zero-fill,
+        # no accumulate kernels); the weight is a view [Co, Ci] of the parameter [Co, Ci, 1, 1], so is its gradient
+        gw = direct_grad(weight)
+        gb = direct_grad(bias) if ctx.has_bias else None
+        direct = gw is not None and (gb is not None or not ctx.has_bias) and gw.is_contiguous()
+        dw = gw if direct else torch.zeros((Co, Ci), dtype=F32, device=a.device)
+        db = gb if (direct and ctx.has_bias) else torch.zeros((Co,), dtype=F32, device=a.device)
         L.check(_k(a).uclstm_outconv_bwd(_p(a), _p(weight), _p(dy), _p(da), _p(dw), _p(db), N, H * W, Cp, Ci, Co, _stream()),
                 "outconv_bwd")
+        if direct:
+            grad_written(weight)
+            if ctx.has_bias:
+                grad_written(bias)
+            return da, None, None
         return da, dw.view_as(weight), (db if ctx.has_bias else None)
 
 
@@ -1251,14 +1278,14 @@ class ConvLSTMSeq(torch.autograd.Function):
             else:
                 igemm_lstm(None if hoist else x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks, pre_add=px_t)
         if need_grad:
-            ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates)
+            ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates, bias)
             ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
-            note_use(weight)
+            note_use(weight, bias)
         return h_hist[1:], c_hist[T]
 
     @staticmethod
     def backward(ctx, dh_all, dc_T):
-        x_all, weight, h_hist, c_hist, gates = ctx.saved_tensors
+        x_all, weight, h_hist, c_hist, gates, bias = ctx.saved_tensors
         Hd, Cx, has_c0, has_bias, ks = ctx.cfg
         T, B, H, W, Cxp = x_all.shape
         Hdp = cpad(Hd)
@@ -1309,8 +1336,10 @@ class ConvLSTMSeq(torch.autograd.Function):
                                                        ud.N, ud.Ktot, (H, W), T * B, ktap=ks, pad=ks // 2))
         dbias = None
         if has_bias:
-            cs = colsum(dg_flat).view(4, Hdp)[:, :Hd]
-            dbias = cs.reshape(4 * Hd).contiguous()
+            if Hdp == Hd:           # dgates columns are (gate, hidden channel) = the bias order of train/unet.py:29
+                dbias = bias_grad_from_colsum(dg_flat, bias, 4 * Hd)
+            else:
+                dbias = colsum(dg_flat).view(4, Hdp)[:, :Hd].reshape(4 * Hd).contiguous()
         dx_all = None
         if ctx.needs_input_grad[0]:
             ddx = lstm_dgrad_pack_desc(Hd, Cx, Cx, ks)
