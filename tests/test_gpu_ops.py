@@ -341,7 +341,7 @@ def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
     got = ops.unpack_wgrad(pd, dwp, w.to(DEV)).cpu()
     wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
     (F.conv2d(xin, wr, None, padding=1) * dy).sum().backward()
-    check_f32(got, wr.grad, "conv3x3 wgrad")
+    check_f32(got, wr.grad, "conv3x3 wgrad", l2=2e-6)          # f32 accumulation of bf16 products: measured 4e-8 .. 6e-7
 
 
 # ---------------------------------------------------------------------------------------------
