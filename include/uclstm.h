@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 8
+#define UCLSTM_ABI_VERSION 9
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -195,11 +195,14 @@ int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, v
  * momentum < 0 means BatchNorm2d(momentum=None): cumulative average, group g uses the factor
  * 1/(-momentum + g), i.e. pass -(num_batches_tracked + 1).
  * `stats` is CONSUMED (its tile-0 slots are overwritten with mean/variance).  stats == NULL:
- * evaluation mode, scale/shift from the running statistics (groups = 1), nothing is updated. */
+ * evaluation mode, scale/shift from the running statistics (groups = 1), nothing is updated.
+ * counters: NULL = two launches (reduction, then the sequential pass); else a DEVICE int32[ceil(Cp/64)] that is zero on
+ * entry and zero again on exit -- one launch: every block finishes its own (group, channel) entries and the last block of a
+ * 64-channel slab (device-scope counter) runs the in-order running-statistics recursion for that slab. */
 int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                            int64_t count_per_group, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps,
-                           float* scale, float* shift, float* mean, float* rstd, void* stream);
+                           float* scale, float* shift, float* mean, float* rstd, int32_t* counters, void* stream);
 /* a = relu(z*scale[g] + shift[g]),  g = pixel / pixels_per_group;  z, a bf16 [pixels][Cp]. */
 int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift,
                              int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
@@ -209,7 +212,11 @@ int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const f
 int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_group);
 int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift,
                              const float* mean, const float* rstd, float* partials, float* sums,
-                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
+                             int64_t pixels, int64_t pixels_per_group, int32_t Cp,
+                             int32_t* counters /* NULL: second kernel adds the rows.  Else DEVICE int32[groups + 1], zero on entry and
+                                                * on exit: ONE launch -- the last block of a group adds that group's rows in row order,
+                                                * and the block completing the last group ADDS the groups into dgamma / dbeta */,
+                             float* dgamma /* [C] or NULL (with counters only) */, float* dbeta, int32_t C, void* stream);
 /* Backward pass 2: dz = scale*(g_ - s1/n - xhat*s2/n)  (bf16). */
 int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, const float* shift,
                             const float* mean, const float* rstd, const float* sums, void* dz,

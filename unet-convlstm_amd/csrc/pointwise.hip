@@ -75,6 +75,78 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(float* __restrict__ sta
     }
 }
 
+// The two passes in ONE launch (18 BatchNorm layers per step: 18 dependent launches less on the main stream).  Every block
+// (group, 64-channel slab) reduces its partial sums as above and writes scale / shift / mean / rstd of its own (group,
+// channel) entries at once -- they need no ordering.  Only the running statistics are a sequential recursion over the groups:
+// the LAST block of a channel slab to finish (device-scope counter per slab, self-resetting) walks the groups in order and
+// applies one momentum step per group, exactly like bn_finalize_kernel below.
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(float* __restrict__ stats, int groups, int tpg, int Cp, int C, double inv_cnt,
+                                                                  double unbias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                  float* __restrict__ rvar, float momentum, float eps,
+                                                                  float* __restrict__ scale, float* __restrict__ shift,
+                                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                                  int* __restrict__ counters) {
+    __shared__ double r1[16][64], r2[16][64];
+    __shared__ int last;
+    const int g = blockIdx.x;
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < Cp) {
+        for (int t = lane; t < tpg; t += 16) {
+            const float2 v = *(const float2*)(stats + (((long)g * tpg + t) * Cp + c) * 2);
+            s1 += v.x;
+            s2 += v.y;
+        }
+    }
+    r1[lane][cl] = s1;
+    r2[lane][cl] = s2;
+    __syncthreads();
+    if (lane == 0 && c < Cp) {
+        s1 = 0.0;
+        s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s1 += r1[k][cl];
+            s2 += r2[k][cl];
+        }
+        const double m = s1 * inv_cnt;
+        double var = s2 * inv_cnt - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        const float mv = (float)m, vv = (float)var;                // the float values the sequential pass reads back
+        *(float2*)(stats + ((long)g * tpg * Cp + c) * 2) = make_float2(mv, vv);
+        const bool real = c < C;
+        const float rs = real ? (float)(1.0 / sqrt((double)vv + (double)eps)) : 0.f;
+        const float sc = real ? gamma[c] * rs : 0.f;
+        const long o = (long)g * Cp + c;
+        scale[o] = sc;
+        shift[o] = real ? beta[c] - mv * sc : 0.f;
+        if (mean_o) mean_o[o] = real ? mv : 0.f;
+        if (rstd_o) rstd_o[o] = rs;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(counters + blockIdx.y, 1) == groups - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (lane == 0 && c < C) {
+        float rm = rmean[c], rv = rvar[c];
+        for (int gg = 0; gg < groups; ++gg) {
+            const float* sp = stats + ((long)gg * tpg * Cp + c) * 2;
+            const float mu = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float var = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)gg);
+            rm = (1.f - mom) * rm + mom * mu;
+            rv = (1.f - mom) * rv + mom * (float)((double)var * unbias);
+        }
+        rmean[c] = rm;
+        rvar[c] = rv;
+    }
+    if (threadIdx.x == 0) counters[blockIdx.y] = 0;            // ready for the next launch on this stream
+}
+
 // Pass 2: per channel, groups IN ORDER (running statistics are a sequential momentum recursion).
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C,
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -158,8 +230,10 @@ static ColGeom col_geom(int Cp) {
 __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, float* __restrict__ partials, int64_t ppg, int Cp, ColGeom cg,
-                                     int blocks_per_group, int64_t pix_per_block) {
+                                     int blocks_per_group, int64_t pix_per_block, float* __restrict__ sums, int* __restrict__ counters,
+                                     int groups, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
     extern __shared__ float red[];     // [rows][cpc*16]
+    __shared__ int tail_flag;
     const int g = blockIdx.x / blocks_per_group;
     const int bi = blockIdx.x - g * blocks_per_group;
     const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
@@ -224,6 +298,56 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
         }
         __syncthreads();
     }
+    if (!counters) return;            // two-launch form: bn_bwd_sum_kernel adds the rows
+    // One-launch form: the LAST block of a group to finish adds the group's partial rows in row order (deterministic; f64),
+    // and the block that completes the LAST group adds the groups into the BatchNorm parameter gradients.  Counters are
+    // device-scope, zero between launches (each is reset by the block that saw it full): counters[1 + g] per group,
+    // counters[0] for the groups.
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) tail_flag = atomicAdd(counters + 1 + g, 1) == blocks_per_group - 1;
+    __syncthreads();
+    if (!tail_flag) return;
+    __threadfence();
+    for (int e = threadIdx.x; e < Cp * 2; e += NT) {
+        double t = 0.0;
+        const float* pp = partials + (long)g * blocks_per_group * Cp * 2 + e;
+        int b = 0;
+        for (; b + 4 <= blocks_per_group; b += 4) {
+            const float v0 = __hip_atomic_load(pp + (long)b * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v1 = __hip_atomic_load(pp + (long)(b + 1) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v2 = __hip_atomic_load(pp + (long)(b + 2) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v3 = __hip_atomic_load(pp + (long)(b + 3) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t += (double)v0;
+            t += (double)v1;
+            t += (double)v2;
+            t += (double)v3;
+        }
+        for (; b < blocks_per_group; ++b) t += (double)__hip_atomic_load(pp + (long)b * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums[(long)g * Cp * 2 + e] = (float)t;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[1 + g] = 0;
+        tail_flag = atomicAdd(counters, 1) == groups - 1;
+    }
+    __syncthreads();
+    if (!tail_flag) return;
+    __threadfence();
+    if (dgamma && dbeta) {
+        for (int c = threadIdx.x; c < C; c += NT) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int gg = 0; gg < groups; ++gg) {
+                const float* sp = sums + ((long)gg * Cp + c) * 2;
+                s1 += __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dbeta[c] += s1;
+            dgamma[c] += s2;
+        }
+    }
+    if (threadIdx.x == 0) counters[0] = 0;
 }
 
 // Same result as bn_bwd_apply_kernel below with the per-(group, channel) constants held in registers: a block owns a pixel
@@ -962,11 +1086,18 @@ __global__ void attn_bwd_dx_kernel(const uint4* __restrict__ dout, const float* 
 extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                                       int64_t count_per_group, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                                      float* rstd, void* stream) {
+                                      float* rstd, int32_t* counters, void* stream) {
     if (groups <= 0 || Cp <= 0 || C <= 0 || C > Cp || !gamma || !beta || !running_mean || !running_var || !scale || !shift)
         return UCLSTM_E_BADARG;
     if (stats && (tiles_per_group <= 0 || count_per_group <= 0)) return UCLSTM_E_BADARG;
     const double unb = (stats && count_per_group > 1) ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
+    if (stats && counters) {
+        // one launch: reduction + scale/shift per (group, channel) + running statistics by the last block of each channel slab
+        UCLSTM_LAUNCH(bn_reduce_finalize_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, groups, tiles_per_group,
+                      Cp, C, 1.0 / (double)count_per_group, unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
+                      rstd, counters);
+        return UCLSTM_OK;
+    }
     if (stats) {
         // the partial-sum buffer is consumed (tile-0 slots are overwritten with mean/variance)
         UCLSTM_LAUNCH(bn_reduce_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, const_cast<float*>(stats),
@@ -1008,18 +1139,20 @@ extern "C" int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_
 
 extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* partials, float* sums, int64_t pixels, int64_t pixels_per_group,
-                                        int32_t Cp, void* stream) {
+                                        int32_t Cp, int32_t* counters, float* dgamma, float* dbeta, int32_t C, void* stream) {
     if (!aligned16(z) || !aligned16(da) || !scale || !shift || !mean || !rstd || !partials || !sums || pixels <= 0 ||
         pixels_per_group <= 0 || (pixels % pixels_per_group) || Cp <= 0 || (Cp % 8))
         return UCLSTM_E_BADARG;
+    if ((dgamma || dbeta) && (!counters || !dgamma || !dbeta || C <= 0 || C > Cp)) return UCLSTM_E_BADARG;
     const ColGeom cg = col_geom(Cp);
     const int groups = (int)(pixels / pixels_per_group);
     const int bpg = bn_bwd_blocks_per_group(pixels_per_group, groups);
     const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
     UCLSTM_LAUNCH(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
-                       scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb);
-    UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
+                       scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb, sums, counters, groups, dgamma, dbeta, C);
+    if (!counters)
+        UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
     return UCLSTM_OK;
 }
 
