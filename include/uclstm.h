@@ -212,11 +212,7 @@ int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const f
 int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_group);
 int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift,
                              const float* mean, const float* rstd, float* partials, float* sums,
-                             int64_t pixels, int64_t pixels_per_group, int32_t Cp,
-                             int32_t* counters /* NULL: second kernel adds the rows.  Else DEVICE int32[groups + 1], zero on entry and
-                                                * on exit: ONE launch -- the last block of a group adds that group's rows in row order,
-                                                * and the block completing the last group ADDS the groups into dgamma / dbeta */,
-                             float* dgamma /* [C] or NULL (with counters only) */, float* dbeta, int32_t C, void* stream);
+                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
 /* Backward pass 2: dz = scale*(g_ - s1/n - xhat*s2/n)  (bf16). */
 int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, const float* shift,
                             const float* mean, const float* rstd, const float* sums, void* dz,

@@ -92,7 +92,7 @@ _PROTOS = {
     "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P],
     "uclstm_bn_apply_relu": [_P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_reduce_rows": [_L, _L],
-    "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _I, _P],
+    "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_param_grads": [_P, _I, _I, _I, _P, _P, _I, _P],
     "uclstm_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],

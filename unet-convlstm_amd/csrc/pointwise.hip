@@ -135,8 +135,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(float* __restr
         float rm = rmean[c], rv = rvar[c];
         for (int gg = 0; gg < groups; ++gg) {
             const float* sp = stats + ((long)gg * tpg * Cp + c) * 2;
-            const float mu = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float var = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // written by other blocks before their counter increment; this block has not read these lines before (no stale
+            // L1 copy) and the fence above orders the loads after the counter
+            const float mu = ((const volatile float*)sp)[0], var = ((const volatile float*)sp)[1];
             const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)gg);
             rm = (1.f - mom) * rm + mom * mu;
             rv = (1.f - mom) * rv + mom * (float)((double)var * unbias);
@@ -230,10 +231,8 @@ static ColGeom col_geom(int Cp) {
 __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, float* __restrict__ partials, int64_t ppg, int Cp, ColGeom cg,
-                                     int blocks_per_group, int64_t pix_per_block, float* __restrict__ sums, int* __restrict__ counters,
-                                     int groups, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+                                     int blocks_per_group, int64_t pix_per_block) {
     extern __shared__ float red[];     // [rows][cpc*16]
-    __shared__ int tail_flag;
     const int g = blockIdx.x / blocks_per_group;
     const int bi = blockIdx.x - g * blocks_per_group;
     const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
@@ -298,56 +297,6 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
         }
         __syncthreads();
     }
-    if (!counters) return;            // two-launch form: bn_bwd_sum_kernel adds the rows
-    // One-launch form: the LAST block of a group to finish adds the group's partial rows in row order (deterministic; f64),
-    // and the block that completes the LAST group adds the groups into the BatchNorm parameter gradients.  Counters are
-    // device-scope, zero between launches (each is reset by the block that saw it full): counters[1 + g] per group,
-    // counters[0] for the groups.
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) tail_flag = atomicAdd(counters + 1 + g, 1) == blocks_per_group - 1;
-    __syncthreads();
-    if (!tail_flag) return;
-    __threadfence();
-    for (int e = threadIdx.x; e < Cp * 2; e += NT) {
-        double t = 0.0;
-        const float* pp = partials + (long)g * blocks_per_group * Cp * 2 + e;
-        int b = 0;
-        for (; b + 4 <= blocks_per_group; b += 4) {
-            const float v0 = __hip_atomic_load(pp + (long)b * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float v1 = __hip_atomic_load(pp + (long)(b + 1) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float v2 = __hip_atomic_load(pp + (long)(b + 2) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float v3 = __hip_atomic_load(pp + (long)(b + 3) * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t += (double)v0;
-            t += (double)v1;
-            t += (double)v2;
-            t += (double)v3;
-        }
-        for (; b < blocks_per_group; ++b) t += (double)__hip_atomic_load(pp + (long)b * Cp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sums[(long)g * Cp * 2 + e] = (float)t;
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        counters[1 + g] = 0;
-        tail_flag = atomicAdd(counters, 1) == groups - 1;
-    }
-    __syncthreads();
-    if (!tail_flag) return;
-    __threadfence();
-    if (dgamma && dbeta) {
-        for (int c = threadIdx.x; c < C; c += NT) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int gg = 0; gg < groups; ++gg) {
-                const float* sp = sums + ((long)gg * Cp + c) * 2;
-                s1 += __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s2 += __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            dbeta[c] += s1;
-            dgamma[c] += s2;
-        }
-    }
-    if (threadIdx.x == 0) counters[0] = 0;
 }
 
 // Same result as bn_bwd_apply_kernel below with the per-(group, channel) constants held in registers: a block owns a pixel
@@ -1139,20 +1088,20 @@ extern "C" int64_t uclstm_bn_bwd_reduce_rows(int64_t pixels, int64_t pixels_per_
 
 extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* partials, float* sums, int64_t pixels, int64_t pixels_per_group,
-                                        int32_t Cp, int32_t* counters, float* dgamma, float* dbeta, int32_t C, void* stream) {
+                                        int32_t Cp, void* stream) {
     if (!aligned16(z) || !aligned16(da) || !scale || !shift || !mean || !rstd || !partials || !sums || pixels <= 0 ||
         pixels_per_group <= 0 || (pixels % pixels_per_group) || Cp <= 0 || (Cp % 8))
         return UCLSTM_E_BADARG;
-    if ((dgamma || dbeta) && (!counters || !dgamma || !dbeta || C <= 0 || C > Cp)) return UCLSTM_E_BADARG;
     const ColGeom cg = col_geom(Cp);
     const int groups = (int)(pixels / pixels_per_group);
     const int bpg = bn_bwd_blocks_per_group(pixels_per_group, groups);
     const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
     UCLSTM_LAUNCH(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
-                       scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb, sums, counters, groups, dgamma, dbeta, C);
-    if (!counters)
-        UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
+                       scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb);
+    // (Folding this second pass into the first with a last-block counter was measured and dropped: one block per group then
+    // adds up to 204 rows while the rest of the chip idles -- the step got 8 ms SLOWER; as its own launch the pass is 8 us.)
+    UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
     return UCLSTM_OK;
 }
 

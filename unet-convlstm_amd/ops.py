@@ -879,9 +879,8 @@ def im2col_first(x: torch.Tensor, time_major: bool) -> torch.Tensor:
     return out
 
 
-# Device-scope "last block finishes the job" counters of the one-launch BatchNorm kernels (uclstm_bn_finalize,
-# uclstm_bn_bwd_reduce): zero between launches (the kernels reset what they used), one buffer per device, forward and
-# backward halves so that a forward launch on one stream can never share counters with a backward launch on another.
+# Device-scope "last block finishes the job" counters of the one-launch BatchNorm statistics kernel (uclstm_bn_finalize):
+# zero between launches (the kernel resets what it used), one buffer per device.
 BN_ONE_LAUNCH = os.environ.get("UCLSTM_BN_ONE_LAUNCH", "1") != "0"
 _BN_COUNTERS: dict = {}
 _BN_COUNTER_SLOTS = 16384
@@ -981,14 +980,9 @@ class ConvBNReLU(torch.autograd.Function):
         sums = torch.empty((groups, Cop, 2), dtype=F32, device=dev)
         partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
         K = _k(z)
-        # one launch: partial sums, their fixed-order addition per group (last block of the group) and -- when gamma / beta own
-        # attached gradient buffers -- the parameter gradients (block that completes the last group)
-        g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
-        cnt = _bn_counters(dev, True, groups + 1)
-        fused_pg = cnt is not None and g_gamma is not None and g_beta is not None
         L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
-                                       _p(cnt), _p(g_gamma) if fused_pg else None, _p(g_beta) if fused_pg else None, Co, _stream()),
-                "bn_bwd_reduce")
+                                       _stream()), "bn_bwd_reduce")
+        g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
         dz = torch.empty_like(z)
         # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
         # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
@@ -999,10 +993,8 @@ class ConvBNReLU(torch.autograd.Function):
         # With frozen statistics it is the column sum of dz.
         bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
         if g_gamma is not None and g_beta is not None:
-            # accumulated straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates): by the
-            # reduction launch above, or by one small kernel when the one-launch form is off
-            if not fused_pg:
-                L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
+            # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates)
+            L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
             dgamma = dbeta = None
             grad_written(gamma)
             grad_written(beta)
