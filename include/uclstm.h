@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 9
+#define UCLSTM_ABI_VERSION 8
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -195,14 +195,11 @@ int32_t uclstm_pack_bias(const uclstm_pack_desc* d, const float* b, float* bp, v
  * momentum < 0 means BatchNorm2d(momentum=None): cumulative average, group g uses the factor
  * 1/(-momentum + g), i.e. pass -(num_batches_tracked + 1).
  * `stats` is CONSUMED (its tile-0 slots are overwritten with mean/variance).  stats == NULL:
- * evaluation mode, scale/shift from the running statistics (groups = 1), nothing is updated.
- * counters: NULL = two launches (reduction, then the sequential pass); else a DEVICE int32[ceil(Cp/64)] that is zero on
- * entry and zero again on exit -- one launch: every block finishes its own (group, channel) entries and the last block of a
- * 64-channel slab (device-scope counter) runs the in-order running-statistics recursion for that slab. */
+ * evaluation mode, scale/shift from the running statistics (groups = 1), nothing is updated. */
 int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                            int64_t count_per_group, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps,
-                           float* scale, float* shift, float* mean, float* rstd, int32_t* counters, void* stream);
+                           float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* a = relu(z*scale[g] + shift[g]),  g = pixel / pixels_per_group;  z, a bf16 [pixels][Cp]. */
 int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift,
                              int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);

@@ -75,79 +75,6 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(float* __restrict__ sta
     }
 }
 
-// The two passes in ONE launch (18 BatchNorm layers per step: 18 dependent launches less on the main stream).  Every block
-// (group, 64-channel slab) reduces its partial sums as above and writes scale / shift / mean / rstd of its own (group,
-// channel) entries at once -- they need no ordering.  Only the running statistics are a sequential recursion over the groups:
-// the LAST block of a channel slab to finish (device-scope counter per slab, self-resetting) walks the groups in order and
-// applies one momentum step per group, exactly like bn_finalize_kernel below.
-__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(float* __restrict__ stats, int groups, int tpg, int Cp, int C, double inv_cnt,
-                                                                  double unbias, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float* __restrict__ rmean,
-                                                                  float* __restrict__ rvar, float momentum, float eps,
-                                                                  float* __restrict__ scale, float* __restrict__ shift,
-                                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                                  int* __restrict__ counters) {
-    __shared__ double r1[16][64], r2[16][64];
-    __shared__ int last;
-    const int g = blockIdx.x;
-    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < Cp) {
-        for (int t = lane; t < tpg; t += 16) {
-            const float2 v = *(const float2*)(stats + (((long)g * tpg + t) * Cp + c) * 2);
-            s1 += v.x;
-            s2 += v.y;
-        }
-    }
-    r1[lane][cl] = s1;
-    r2[lane][cl] = s2;
-    __syncthreads();
-    if (lane == 0 && c < Cp) {
-        s1 = 0.0;
-        s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            s1 += r1[k][cl];
-            s2 += r2[k][cl];
-        }
-        const double m = s1 * inv_cnt;
-        double var = s2 * inv_cnt - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        const float mv = (float)m, vv = (float)var;                // the float values the sequential pass reads back
-        *(float2*)(stats + ((long)g * tpg * Cp + c) * 2) = make_float2(mv, vv);
-        const bool real = c < C;
-        const float rs = real ? (float)(1.0 / sqrt((double)vv + (double)eps)) : 0.f;
-        const float sc = real ? gamma[c] * rs : 0.f;
-        const long o = (long)g * Cp + c;
-        scale[o] = sc;
-        shift[o] = real ? beta[c] - mv * sc : 0.f;
-        if (mean_o) mean_o[o] = real ? mv : 0.f;
-        if (rstd_o) rstd_o[o] = rs;
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(counters + blockIdx.y, 1) == groups - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    if (lane == 0 && c < C) {
-        float rm = rmean[c], rv = rvar[c];
-        for (int gg = 0; gg < groups; ++gg) {
-            const float* sp = stats + ((long)gg * tpg * Cp + c) * 2;
-            // written by other blocks before their counter increment; this block has not read these lines before (no stale
-            // L1 copy) and the fence above orders the loads after the counter
-            const float mu = ((const volatile float*)sp)[0], var = ((const volatile float*)sp)[1];
-            const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)gg);
-            rm = (1.f - mom) * rm + mom * mu;
-            rv = (1.f - mom) * rv + mom * (float)((double)var * unbias);
-        }
-        rmean[c] = rm;
-        rvar[c] = rv;
-    }
-    if (threadIdx.x == 0) counters[blockIdx.y] = 0;            // ready for the next launch on this stream
-}
-
 // Pass 2: per channel, groups IN ORDER (running statistics are a sequential momentum recursion).
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C,
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1035,18 +962,11 @@ __global__ void attn_bwd_dx_kernel(const uint4* __restrict__ dout, const float* 
 extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
                                       int64_t count_per_group, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                                      float* rstd, int32_t* counters, void* stream) {
+                                      float* rstd, void* stream) {
     if (groups <= 0 || Cp <= 0 || C <= 0 || C > Cp || !gamma || !beta || !running_mean || !running_var || !scale || !shift)
         return UCLSTM_E_BADARG;
     if (stats && (tiles_per_group <= 0 || count_per_group <= 0)) return UCLSTM_E_BADARG;
     const double unb = (stats && count_per_group > 1) ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
-    if (stats && counters) {
-        // one launch: reduction + scale/shift per (group, channel) + running statistics by the last block of each channel slab
-        UCLSTM_LAUNCH(bn_reduce_finalize_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, groups, tiles_per_group,
-                      Cp, C, 1.0 / (double)count_per_group, unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
-                      rstd, counters);
-        return UCLSTM_OK;
-    }
     if (stats) {
         // the partial-sum buffer is consumed (tile-0 slots are overwritten with mean/variance)
         UCLSTM_LAUNCH(bn_reduce_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, const_cast<float*>(stats),
@@ -1099,8 +1019,6 @@ extern "C" int32_t uclstm_bn_bwd_reduce(const void* z, const void* da, const flo
     const size_t lds = (size_t)cg.rows * (cg.cpc < NT ? cg.cpc : NT) * 16 * sizeof(float);
     UCLSTM_LAUNCH(bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, partials, pixels_per_group, Cp, cg, bpg, ppb);
-    // (Folding this second pass into the first with a last-block counter was measured and dropped: one block per group then
-    // adds up to 204 rows while the rest of the chip idles -- the step got 8 ms SLOWER; as its own launch the pass is 8 us.)
     UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
     return UCLSTM_OK;
 }

@@ -879,22 +879,6 @@ def im2col_first(x: torch.Tensor, time_major: bool) -> torch.Tensor:
     return out
 
 
-# Device-scope "last block finishes the job" counters of the one-launch BatchNorm statistics kernel (uclstm_bn_finalize):
-# zero between launches (the kernel resets what it used), one buffer per device.
-BN_ONE_LAUNCH = os.environ.get("UCLSTM_BN_ONE_LAUNCH", "1") != "0"
-_BN_COUNTERS: dict = {}
-_BN_COUNTER_SLOTS = 16384
-
-
-def _bn_counters(dev, backward: bool, need: int) -> Optional[torch.Tensor]:
-    if not BN_ONE_LAUNCH or need > _BN_COUNTER_SLOTS or torch.cuda.is_current_stream_capturing() and str(dev) not in _BN_COUNTERS:
-        return None
-    buf = _BN_COUNTERS.get(str(dev))
-    if buf is None:
-        buf = _BN_COUNTERS[str(dev)] = torch.zeros((2, _BN_COUNTER_SLOTS), dtype=torch.int32, device=dev)
-    return buf[1 if backward else 0]
-
-
 # ---------------------------------------------------------------------------------------------
 # conv3x3 (+ optional second source) + BatchNorm + ReLU   (train/unet.py:70-71, :98)
 # ---------------------------------------------------------------------------------------------
@@ -938,7 +922,7 @@ class ConvBNReLU(torch.autograd.Function):
             par = torch.empty((4, groups, Cop), dtype=F32, device=dev)     # scale, shift, mean, rstd
             L.check(L.lib.uclstm_bn_finalize(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), _p(running_mean),
                                              _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
-                                             _p(_bn_counters(dev, False, (Cop + 63) // 64)), _stream()), "bn_finalize")
+                                             _stream()), "bn_finalize")
             a = torch.empty_like(z)
             L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
                     "bn_apply_relu")
@@ -952,7 +936,7 @@ class ConvBNReLU(torch.autograd.Function):
             igemm_store(srcs, wp, (H, W), n_img, [(z, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp)
             par = torch.empty((4, 1, Cop), dtype=F32, device=dev)
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                             momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), None, _stream()), "bn_finalize(eval)")
+                                             momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _stream()), "bn_finalize(eval)")
             a = torch.empty_like(z)
             L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, n_img * H * W, Cop, _stream()),
                     "bn_apply_relu")
@@ -961,7 +945,7 @@ class ConvBNReLU(torch.autograd.Function):
         else:
             par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                             momentum, eps, _p(par[0]), _p(par[1]), None, None, None, _stream()), "bn_finalize(eval)")
+                                             momentum, eps, _p(par[0]), _p(par[1]), None, None, _stream()), "bn_finalize(eval)")
             a = out
             igemm_store(srcs, wp, (H, W), n_img, [(a, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp,
                         col_scale=par[0], col_shift=par[1], relu=True)
@@ -981,8 +965,7 @@ class ConvBNReLU(torch.autograd.Function):
         partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
         K = _k(z)
         L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
-                                       _stream()), "bn_bwd_reduce")
-        g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
+                                           _stream()), "bn_bwd_reduce")
         dz = torch.empty_like(z)
         # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
         # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
@@ -992,6 +975,7 @@ class ConvBNReLU(torch.autograd.Function):
         # training: the conv bias feeds BatchNorm, which removes any per-channel constant -- its gradient is analytically 0.
         # With frozen statistics it is the column sum of dz.
         bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
+        g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
         if g_gamma is not None and g_beta is not None:
             # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates)
             L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
