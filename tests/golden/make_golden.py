@@ -385,6 +385,25 @@ def gen_resnet_lstms():
     save("ref_resnet_lstms", **arr)
 
 
+def gen_cell_k():
+    """ConvLSTM with 5x5 and 7x7 gate convolutions (the reference accepts any kernel_size, train/unet.py:15-19; every call
+    site uses 3): T=3 sequence, outputs, final state, all gradients."""
+    arr = {}
+    for k, seed in ((5, 1000), (7, 1001)):
+        torch.manual_seed(seed)
+        lstm = ConvLSTM(4, 8, num_layers=1, kernel_size=k)
+        xs = [torch.randn(2, 4, 10, 9, requires_grad=True) for _ in range(3)]
+        outs, st = lstm(xs)
+        (sum((o * o).sum() for o in outs) * 0.5 + st[0][1].sum()).backward()
+        arr.update({f"k{k}/p/{n}": npy(v) for n, v in lstm.state_dict().items()})
+        arr.update({f"k{k}/g/{n}": npy(v.grad) for n, v in lstm.named_parameters()})
+        arr[f"k{k}/x"] = np.stack([npy(x) for x in xs])
+        arr[f"k{k}/gx"] = np.stack([npy(x.grad) for x in xs])
+        arr[f"k{k}/out"] = np.stack([npy(o) for o in outs])
+        arr[f"k{k}/c_final"] = npy(st[0][1])
+    save("cell_k", **arr)
+
+
 SEEDED = {
     # BASELINE configs[1] at the benchmark's own batch (the kernel plan the driver times): base_ch 64 + skip LSTMs, B=32
     "ref_cfg1_b32": dict(base_ch=64, skip=True, B=32, T=2, HW=64, kind="uniform", seed=900, use_mask=False),

@@ -797,3 +797,22 @@ def test_spatial_attention_forward_backward_vs_oracle(N, C, H, W, k, dtype):
     e_y, e_x, e_w = rel_l2(y.detach().cpu(), yr.detach()), rel_l2(xd.grad.cpu(), xr.grad), rel_l2(sa.conv.weight.grad.cpu(), wr.grad)
     print(f"[parity] SpatialAttention {dtype} C={C} {H}x{W} k={k}: out {e_y:.2e}, dx {e_x:.2e}, dw {e_w:.2e}")
     assert e_y <= tol and e_x <= 2 * tol and e_w <= 2 * tol
+
+
+@pytest.mark.parametrize("k", [5, 7])
+def test_convlstm_5x5_and_7x7_gate_convolutions_golden(k):
+    """ConvLSTM(kernel_size=5 / 7) against the reference's own outputs and gradients (round 1 refused kernel sizes other than 1
+    and 3): the per-tap GEMM loop with 25 / 49 taps, the generic weight-gradient kernel and the generic pack map."""
+    g = sub(load_golden("cell_k"), f"k{k}/")
+    lstm = U.ConvLSTM(4, 8, num_layers=1, kernel_size=k).to(DEV)
+    lstm.load_state_dict(sub(g, "p/"))
+    xs = [g["x"][t].to(DEV).requires_grad_(True) for t in range(3)]
+    outs, st = lstm(xs)
+    (sum((o * o).sum() for o in outs) * 0.5 + st[0][1].sum()).backward()
+    check_bf16(torch.stack([o.detach().cpu() for o in outs]), g["out"], f"ConvLSTM k={k} out", l2=1e-2, mx=5e-2)
+    check_f32(st[0][1].detach().cpu(), g["c_final"], f"ConvLSTM k={k} c_final", l2=1e-2)
+    check_f32(torch.stack([x.grad.cpu() for x in xs]), g["gx"], f"ConvLSTM k={k} dx", l2=3e-2)
+    for n, v in lstm.named_parameters():
+        check_f32(v.grad.cpu(), g["g/" + n], f"ConvLSTM k={k} grad " + n, l2=3e-2)
+    with pytest.raises(U.UclstmError):
+        U.ConvLSTMCell(4, 8, kernel_size=4)

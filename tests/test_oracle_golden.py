@@ -281,3 +281,17 @@ def test_oracle_resnet18_convlstms(ch, hw, seed):
     torch.testing.assert_close(norms, g[f"{tag}/grad_norms"], rtol=1e-3, atol=1e-9)
     assert rel_l2(p["lstm.layers.0.conv.bias"].grad, g[f"{tag}/gbias0"]) <= 1e-4
     assert rel_l2(p["lstm.layers.1.conv.weight"].grad[:8, :8], g[f"{tag}/gw1_slice"]) <= 1e-4
+
+
+@pytest.mark.parametrize("k", [5, 7])
+def test_oracle_convlstm_with_5x5_and_7x7_gate_convolutions(k):
+    g = sub(load_golden("cell_k"), f"k{k}/")
+    p = {"l." + n: v.clone().requires_grad_(True) for n, v in sub(g, "p/").items()}
+    xs = [g["x"][t].clone().requires_grad_(True) for t in range(3)]
+    outs, st = O.convlstm(xs, p, "l", 1)
+    close(torch.stack(outs), g["out"])
+    close(st[0][1], g["c_final"])
+    (sum((o * o).sum() for o in outs) * 0.5 + st[0][1].sum()).backward()
+    close(torch.stack([x.grad for x in xs]), g["gx"], rtol=1e-3, atol=1e-4)
+    for n, v in p.items():
+        close(v.grad, g["g/" + n[2:]], rtol=1e-3, atol=2e-4)

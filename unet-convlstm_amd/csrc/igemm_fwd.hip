@@ -325,8 +325,10 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
 
     // per staged row: byte offset of tap (0,0) in each source (descriptor-relative, never negative), and a bit mask of the
     // taps that fall OUTSIDE the image (all ones for rows beyond the tile's last pixel)
+    // (two 32-bit mask words: kernels up to 7x7 = 49 taps -- ConvLSTMCell accepts any odd kernel_size, train/unet.py:15-19;
+    //  word 1 is only ever non-trivial for 7x7)
     uint32_t roff0[XR], roff1[XR];
-    uint32_t nv0[XR], nv1[XR];
+    uint32_t nv0[XR], nv1[XR], nv0h[XR], nv1h[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int r = lrow0 + RS * i;
@@ -342,20 +344,21 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
             const int ys0 = y * d.scale - d.pad - S.offY;
             const int xs0 = x * d.scale - d.pad - S.offX;
             const uint32_t ro = (uint32_t)(2 * (((img * S.Hs + ys0) * S.Ws + xs0) * S.C + lchunk * 8) + (int)dv.xbias[sidx]);
-            uint32_t mk = 0;
+            uint64_t mk = 0;
             if (rvalid) {
-                // tap (j,k) is inside the image iff row j and column k are: 3 + 3 compares, no division
-                uint32_t colm = 0;
+                // tap (j,k) is inside the image iff row j and column k are: ktap + ktap compares, no division
+                uint64_t colm = 0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1u << k;
+                for (int k = 0; k < 7; ++k)
+                    if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1ull << k;
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 7; ++j)
                     if (j < d.ktap && (unsigned)(ys0 + j) < (unsigned)S.Hs) mk |= colm << (j * d.ktap);
             }
             // a lane whose channel chunk lies beyond a narrow source (C < 64) is never valid
             if (lchunk * 8 >= S.C) mk = 0;
-            if (sidx == 0) { roff0[i] = ro; nv0[i] = ~mk; } else { roff1[i] = ro; nv1[i] = ~mk; }
+            if (sidx == 0) { roff0[i] = ro; nv0[i] = ~(uint32_t)mk; nv0h[i] = ~(uint32_t)(mk >> 32); }
+            else { roff1[i] = ro; nv1[i] = ~(uint32_t)mk; nv1h[i] = ~(uint32_t)(mk >> 32); }
         }
     }
     // weight panel rows: loop-invariant offsets, the K-step advances through soffset (rows >= N read zeros)
@@ -392,14 +395,17 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         const __amdgpu_buffer_rsrc_t rs = s1 ? rsx1 : rsx0;
         const int tdy = tap / d.ktap;
         const uint32_t tapoff = (uint32_t)(2 * ((tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0));      // wave-uniform -> soffset
-        const uint32_t sh = 31u - (uint32_t)tap;
+        const bool hiw = tap >= 32;                              // wave-uniform: second mask word (7x7 kernels only)
+        const uint32_t sh = 31u - (uint32_t)(tap & 31);
         // channels beyond a source whose width is not a multiple of 64: only the last K-step of its segment can see them
         uint32_t cbad = 0;
         if ((S.C & 63) && c0 + 64 > S.C) cbad = (c0 + lchunk * 8 >= S.C) ? OOB : 0u;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const uint32_t ro = (NSRC > 1) ? (s1 ? roff1[i] : roff0[i]) : roff0[i];
-            const uint32_t nv = (NSRC > 1) ? (s1 ? nv1[i] : nv0[i]) : nv0[i];
+            const uint32_t nvl = (NSRC > 1) ? (s1 ? nv1[i] : nv0[i]) : nv0[i];
+            const uint32_t nvh = (NSRC > 1) ? (s1 ? nv1h[i] : nv0h[i]) : nv0h[i];
+            const uint32_t nv = hiw ? nvh : nvl;
             // bit `tap` of the outside-mask -> bit 31 of the offset: out of range, the DMA writes zeros
             const uint32_t off = (((nv << sh) & OOB) | ro) | cbad;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(X + i * RS * 128 + wrow_lds), 16, off, tapoff, 0, 0);
@@ -1074,7 +1080,7 @@ extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit) {
 // Validation + launch plan shared by uclstm_igemm_fwd and uclstm_igemm_fwd_shape: derived constants, block shape, grid.
 static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64_t& nblk, int64_t& mg_out) {
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0 || d.groups <= 0 || d.n_img % d.groups) return UCLSTM_E_BADARG;
-    if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
+    if (d.ktap < 1 || d.ktap > 7 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 3) return UCLSTM_E_BADARG;
     if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
     for (int s = 0; s < d.nsrc; ++s)
         if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;

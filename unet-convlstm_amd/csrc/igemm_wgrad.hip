@@ -794,7 +794,7 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
     if (!dp) return UCLSTM_E_BADARG;
     const uclstm_wgrad_desc& d = *dp;
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0) return UCLSTM_E_BADARG;
-    if (d.ktap < 1 || d.ktap > 3 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 1) return UCLSTM_E_BADARG;
+    if (d.ktap < 1 || d.ktap > 7 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 3) return UCLSTM_E_BADARG;
     if (d.nsrc < 1 || d.nsrc > 2 || (!d.dwp && !plan_only) || d.N <= 0 || (d.N % 8) || d.splits < 0 || d.slab < 0) return UCLSTM_E_BADARG;
     if (d.slab > 0 && d.slab < (int64_t)d.N * d.Ktot) return UCLSTM_E_BADARG;
     if (d.nseg < 1 || d.nseg > 4) return UCLSTM_E_BADARG;

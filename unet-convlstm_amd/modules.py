@@ -36,8 +36,10 @@ class ConvLSTMCell(nn.Module):
 
     def __init__(self, input_dim, hidden_dim, kernel_size=3, bias=True):
         super().__init__()
-        if kernel_size not in (1, 3):
-            raise UclstmError("ConvLSTMCell: the HIP path supports kernel_size 1 or 3 (every reference call site uses 3)")
+        if kernel_size % 2 == 0 or not 1 <= kernel_size <= 7:
+            # an even kernel with padding k//2 grows the map by one pixel per step: the reference's own cell update
+            # (train/unet.py:34) then fails on shapes; the GEMM staging holds tap masks for up to 7x7 = 49 taps
+            raise UclstmError("ConvLSTMCell: kernel_size must be odd and <= 7")
         padding = kernel_size // 2
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim
