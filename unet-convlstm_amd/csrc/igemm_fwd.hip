@@ -91,7 +91,9 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int EPI, int SHP, int NSRC>
+// KT = widest kernel the per-tap loop's tap masks cover: 3 (one 32-bit word, the hot path) or 7 (two words: ConvLSTM cells
+// with 5x5 / 7x7 gate convolutions, 128 x 128 shape only).
+template <int EPI, int SHP, int NSRC, int KT = 3>
 __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
     using SH = Shape<SHP>;
@@ -325,10 +327,10 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
 
     // per staged row: byte offset of tap (0,0) in each source (descriptor-relative, never negative), and a bit mask of the
     // taps that fall OUTSIDE the image (all ones for rows beyond the tile's last pixel)
-    // (two 32-bit mask words: kernels up to 7x7 = 49 taps -- ConvLSTMCell accepts any odd kernel_size, train/unet.py:15-19;
-    //  word 1 is only ever non-trivial for 7x7)
+    // (KT = 7: two 32-bit mask words for up to 7x7 = 49 taps -- ConvLSTMCell accepts any odd kernel_size, train/unet.py:15-19)
+    constexpr int XRH = KT > 3 ? XR : 1;
     uint32_t roff0[XR], roff1[XR];
-    uint32_t nv0[XR], nv1[XR], nv0h[XR], nv1h[XR];
+    uint32_t nv0[XR], nv1[XR], nv0h[XRH], nv1h[XRH];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int r = lrow0 + RS * i;
@@ -349,16 +351,18 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
                 // tap (j,k) is inside the image iff row j and column k are: ktap + ktap compares, no division
                 uint64_t colm = 0;
 #pragma unroll
-                for (int k = 0; k < 7; ++k)
+                for (int k = 0; k < KT; ++k)
                     if (k < d.ktap && (unsigned)(xs0 + k) < (unsigned)S.Ws) colm |= 1ull << k;
 #pragma unroll
-                for (int j = 0; j < 7; ++j)
+                for (int j = 0; j < KT; ++j)
                     if (j < d.ktap && (unsigned)(ys0 + j) < (unsigned)S.Hs) mk |= colm << (j * d.ktap);
             }
             // a lane whose channel chunk lies beyond a narrow source (C < 64) is never valid
             if (lchunk * 8 >= S.C) mk = 0;
-            if (sidx == 0) { roff0[i] = ro; nv0[i] = ~(uint32_t)mk; nv0h[i] = ~(uint32_t)(mk >> 32); }
-            else { roff1[i] = ro; nv1[i] = ~(uint32_t)mk; nv1h[i] = ~(uint32_t)(mk >> 32); }
+            if (sidx == 0) { roff0[i] = ro; nv0[i] = ~(uint32_t)mk; } else { roff1[i] = ro; nv1[i] = ~(uint32_t)mk; }
+            if constexpr (KT > 3) {
+                if (sidx == 0) nv0h[i] = ~(uint32_t)(mk >> 32); else nv1h[i] = ~(uint32_t)(mk >> 32);
+            }
         }
     }
     // weight panel rows: loop-invariant offsets, the K-step advances through soffset (rows >= N read zeros)
@@ -395,17 +399,19 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
         const __amdgpu_buffer_rsrc_t rs = s1 ? rsx1 : rsx0;
         const int tdy = tap / d.ktap;
         const uint32_t tapoff = (uint32_t)(2 * ((tdy * S.Ws + (tap - tdy * d.ktap)) * S.C + c0));      // wave-uniform -> soffset
-        const bool hiw = tap >= 32;                              // wave-uniform: second mask word (7x7 kernels only)
-        const uint32_t sh = 31u - (uint32_t)(tap & 31);
+        const bool hiw = KT > 3 && tap >= 32;                    // wave-uniform: second mask word (7x7 kernels only)
+        const uint32_t sh = 31u - (uint32_t)(KT > 3 ? (tap & 31) : tap);
         // channels beyond a source whose width is not a multiple of 64: only the last K-step of its segment can see them
         uint32_t cbad = 0;
         if ((S.C & 63) && c0 + 64 > S.C) cbad = (c0 + lchunk * 8 >= S.C) ? OOB : 0u;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const uint32_t ro = (NSRC > 1) ? (s1 ? roff1[i] : roff0[i]) : roff0[i];
-            const uint32_t nvl = (NSRC > 1) ? (s1 ? nv1[i] : nv0[i]) : nv0[i];
-            const uint32_t nvh = (NSRC > 1) ? (s1 ? nv1h[i] : nv0h[i]) : nv0h[i];
-            const uint32_t nv = hiw ? nvh : nvl;
+            uint32_t nv = (NSRC > 1) ? (s1 ? nv1[i] : nv0[i]) : nv0[i];
+            if constexpr (KT > 3) {
+                const uint32_t nvh = (NSRC > 1) ? (s1 ? nv1h[i] : nv0h[i]) : nv0h[i];
+                nv = hiw ? nvh : nv;
+            }
             // bit `tap` of the outside-mask -> bit 31 of the offset: out of range, the DMA writes zeros
             const uint32_t off = (((nv << sh) & OOB) | ro) | cbad;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(X + i * RS * 128 + wrow_lds), 16, off, tapoff, 0, 0);
@@ -1041,19 +1047,22 @@ inline int patch_ok(const uclstm_igemm_desc& d, int64_t mg) {
     return 0;
 }
 
-template <int EPI, int SHP, int NSRC>
+template <int EPI, int SHP, int NSRC, int KT = 3>
 int32_t launch_n(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
-    static bool attr_done = false;
+    static bool attr_done = false;          // per process: one process per GPU
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, SHP, NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)igemm_fwd_kernel<EPI, SHP, NSRC, KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    Shape<SHP>::SMEM);
         attr_done = true;
     }
-    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, SHP, NSRC>), dim3((unsigned)nblk), dim3(Shape<SHP>::NT), Shape<SHP>::SMEM, st, d, dv);
+    UCLSTM_LAUNCH((igemm_fwd_kernel<EPI, SHP, NSRC, KT>), dim3((unsigned)nblk), dim3(Shape<SHP>::NT), Shape<SHP>::SMEM, st, d, dv);
     return UCLSTM_OK;
 }
 template <int EPI, int SHP>
 int32_t launch(const uclstm_igemm_desc& d, const Derived& dv, int64_t nblk, hipStream_t st) {
+    if constexpr (SHP == 0) {
+        if (d.ktap > 3) return d.nsrc == 1 ? launch_n<EPI, 0, 1, 7>(d, dv, nblk, st) : launch_n<EPI, 0, 2, 7>(d, dv, nblk, st);
+    }
     return d.nsrc == 1 ? launch_n<EPI, SHP, 1>(d, dv, nblk, st) : launch_n<EPI, SHP, 2>(d, dv, nblk, st);
 }
 
@@ -1082,6 +1091,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0 || d.groups <= 0 || d.n_img % d.groups) return UCLSTM_E_BADARG;
     if (d.ktap < 1 || d.ktap > 7 || d.scale < 1 || d.scale > 2 || d.pad < 0 || d.pad > 3) return UCLSTM_E_BADARG;
     if (d.nsrc < 1 || d.nsrc > 2 || !d.wp || d.N <= 0 || (d.N % 8)) return UCLSTM_E_BADARG;
+    if (d.ktap > 3 && d.epi == UCLSTM_EPI_STORE && d.stats) return UCLSTM_E_BADARG;      // statistics rows are laid out for the 3x3 shapes
     for (int s = 0; s < d.nsrc; ++s)
         if (!src_ok(d.src[s])) return UCLSTM_E_BADARG;
     dv = Derived{};
@@ -1106,7 +1116,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     if (mg * d.groups >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));
     dv.dW = make_fastdiv((uint32_t)d.W);
-    shp = pick_shape(d.N, mg, d.groups, d.epi);
+    shp = d.ktap > 3 ? 0 : pick_shape(d.N, mg, d.groups, d.epi);      // kernels wider than 3x3: the 128 x 128 shape only
     mg_out = mg;
     int patch = patch_ok(d, mg);
     if (patch && d.epi == UCLSTM_EPI_ATOMIC) {            // K ranges must be whole 64-channel chunks (9 taps each)
