@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0              # HBM3E, same guide
 TRAFFIC_FILE = "round2_hbm_traffic.json"
 TRAFFIC_NOTE = (f"committed PMC passes (profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of "
                 "this command, gfx950 correction applied); NOT measured in this run")
@@ -249,6 +250,7 @@ def main():
         # EVERY rank runs it (the step contains the gradient all-reduce); only rank 0 records events.
         async_was, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
         ops.PROFILE = [] if rank == 0 else None
+        ops.PROFILE_HBM = [] if rank == 0 else None
         step()
         torch.cuda.synchronize()
         ops.ASYNC_WGRAD = async_was
@@ -263,6 +265,13 @@ def main():
             k[1] += t_ms
             k[2] += 1
         ops.PROFILE = None
+        hbm = {}
+        for kind, nbytes, e0, e1, _ in (ops.PROFILE_HBM or []):
+            k = hbm.setdefault(kind, [0.0, 0.0, 0])
+            k[0] += nbytes
+            k[1] += e0.elapsed_time(e1)
+            k[2] += 1
+        ops.PROFILE_HBM = None
         if a.dump_launches:
             merged = {}
             for t_ms, kind, flops, note in rows:
@@ -291,7 +300,11 @@ def main():
                     "launches": n, "timing": "HIP events, one serialised step (side stream off)",
                     "avg_launch_ms": round(ms / n, 4),
                     "all": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
-                            for k, v in agg.items()}}
+                            for k, v in agg.items()},
+                    # the HBM-bound kernels of the same step against the 8 TB/s HBM roofline: ALGORITHMIC bytes (each tensor
+                    # read or written once) / HIP-event time
+                    "hbm_bound": {k: {"gbs": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
+                                      "ms": round(v[1], 3), "launches": v[2]} for k, v in hbm.items()}}
     if world > 1:
         dist.barrier()
 

@@ -105,6 +105,22 @@ def _log_shape(d) -> None:
             KERNEL_LOG.append((int(d.epi), shp))
 
 
+# Same for the HBM-bound kernels (BatchNorm passes, pooling, LSTM point-wise): (kernel, algorithmic BYTES, start, stop, note).
+PROFILE_HBM: Optional[list] = None
+
+
+def _timed_hbm(kind: str, nbytes: float, launch) -> None:
+    if PROFILE_HBM is None:
+        launch()
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE_HBM.append((kind, nbytes, e0, e1, ""))
+
+
 def _timed(kind: str, flops: float, launch, note: str = "") -> None:
     if PROFILE is None:
         launch()
@@ -924,10 +940,12 @@ class ConvBNReLU(torch.autograd.Function):
                                              _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
                                              _stream()), "bn_finalize")
             a = torch.empty_like(z)
-            L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
-                    "bn_apply_relu")
+            _timed_hbm("bn_apply_relu", 4.0 * z.numel(),        # 2 B read + 2 B written per element
+                       lambda: L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
+                                       "bn_apply_relu"))
             ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
-            note_use(weight, gamma, beta, bias)
+            if need_bw:
+                note_use(weight, gamma, beta, bias)
         elif need_bw:
             # evaluation-mode statistics WITH a backward pass (fine-tuning through frozen BatchNorm): keep the pre-BN conv
             # output like the training path does, normalise with the running statistics as one group
@@ -964,14 +982,16 @@ class ConvBNReLU(torch.autograd.Function):
         sums = torch.empty((groups, Cop, 2), dtype=F32, device=dev)
         partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
         K = _k(z)
-        L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums), pixels, ppg, Cop,
-                                           _stream()), "bn_bwd_reduce")
+        _timed_hbm("bn_bwd_reduce", 4.0 * z.numel(),            # z and da read once
+                   lambda: L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums),
+                                                          pixels, ppg, Cop, _stream()), "bn_bwd_reduce"))
         dz = torch.empty_like(z)
         # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
         # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
         sums_dz = sums if training else torch.zeros_like(sums)
-        L.check(K.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz), pixels, ppg,
-                                          Cop, _stream()), "bn_bwd_apply")
+        _timed_hbm("bn_bwd_apply", 6.0 * z.numel(),             # z, da read, dz written
+                   lambda: L.check(K.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz),
+                                                         pixels, ppg, Cop, _stream()), "bn_bwd_apply"))
         # training: the conv bias feeds BatchNorm, which removes any per-channel constant -- its gradient is analytically 0.
         # With frozen statistics it is the column sum of dz.
         bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
