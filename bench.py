@@ -62,6 +62,9 @@ def parse():
                          "in a rocprofv3 trace are then free of side-stream overlap and agree with the roofline leg)")
     ap.add_argument("--dump-launches", action="store_true", help="per-shape table of the instrumented step (stderr)")
     ap.add_argument("--bf16-buckets", action="store_true", help="FlatDDP exchanges gradients as bf16 (half the bytes over xGMI)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="developer rehearsal of the N-rank flow on a 1-GPU box: every rank uses cuda:0 and the collectives go over "
+                         "gloo (RCCL refuses two ranks on one device); the number it prints is NOT a scaling measurement")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendezvous over gloo on the CPU, report what every rank saw and exit (no GPU work): "
                          "the CPU test of the launch contract")
@@ -81,7 +84,7 @@ def self_launch(a) -> int:
     JSON line on the inherited stdout."""
     if not a.dry_launch:
         have = torch.cuda.device_count()          # counts devices without creating a HIP context
-        if have < a.gpus:
+        if have < a.gpus and not (a.rehearse_on_one_gpu and have >= 1):
             print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
@@ -186,11 +189,15 @@ def main():
         return dry_launch(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1 or a.force_ddp:
-        if "RANK" not in os.environ:                      # single process without torchrun
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        elif "RANK" not in os.environ:                    # single process without torchrun
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -320,6 +327,7 @@ def main():
                                    f"{a.size}x{a.size} seq-{a.seq}, per-GPU batch {a.batch}, AdamW+clip",
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            **({"rehearsal": "all ranks on cuda:0, collectives over gloo -- not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
             "final_loss": round(lossv, 5),
         }
         if gf is not None:
