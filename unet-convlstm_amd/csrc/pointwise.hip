@@ -178,20 +178,24 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
             load8f(mean + so, mu);
             load8f(rstd + so, rs);
             int64_t p = p0 + prow;
-            for (; p + cg.rows < p1; p += 2 * cg.rows) {       // two pixel rows (four 16-byte loads) in flight
-                const uint4 za = z[p * cg.cpc + cc], ga = da[p * cg.cpc + cc];
-                const uint4 zb = z[(p + cg.rows) * cg.cpc + cc], gb = da[(p + cg.rows) * cg.cpc + cc];
-                float zv[8], gv[8], zw[8], gw[8];
-                unpack8(za, zv);
-                unpack8(ga, gv);
-                unpack8(zb, zw);
-                unpack8(gb, gw);
+            for (; p + 3 * cg.rows < p1; p += 4 * cg.rows) {       // four pixel rows (eight 16-byte loads) in flight
+                uint4 zq[4], gq[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float g0 = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
-                    const float g1 = (zw[i] * sc[i] + sh[i] > 0.f) ? gw[i] : 0.f;
-                    s1[i] += g0 + g1;
-                    s2[i] += (g0 * (zv[i] - mu[i]) + g1 * (zw[i] - mu[i])) * rs[i];
+                for (int u = 0; u < 4; ++u) {
+                    zq[u] = z[(p + u * cg.rows) * cg.cpc + cc];
+                    gq[u] = da[(p + u * cg.rows) * cg.cpc + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float zv[8], gv[8];
+                    unpack8(zq[u], zv);
+                    unpack8(gq[u], gv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float g0 = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
+                        s1[i] += g0;
+                        s2[i] += g0 * (zv[i] - mu[i]) * rs[i];
+                    }
                 }
             }
             for (; p < p1; p += cg.rows) {
@@ -991,8 +995,9 @@ extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* sca
 
 namespace {
 inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
+    static const int total = [] { const char* e = getenv("UCLSTM_BN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
     int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
-    const int cap = (4096 + groups - 1) / groups;
+    const int cap = (total + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
     return bpg < 1 ? 1 : bpg;
 }
