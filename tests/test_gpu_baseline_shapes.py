@@ -209,3 +209,37 @@ def test_resnet18_convlstms_vs_reference(ch, hw, seed):
     print(f"[parity] resnet18 ConvLSTM ch={ch} {hw}x{hw}: out {e_out:.5f}, d/dfeatures {e_g:.5f}, gradient norms {e_n:.5f}, "
           f"layer-0 bias gradient {e_b:.5f}, layer-1 weight-gradient slice {e_w:.5f}")
     assert e_out <= 1e-2 and e_g <= 3e-2 and e_n <= 3e-2 and e_b <= 3e-2 and e_w <= 3e-2
+
+
+def test_config1_full_size_properties():
+    """BASELINE configs[1] at its FULL size (base_ch 64 + skip LSTMs, B=32, T=20, 64x64 -- too large for the CPU oracle in a
+    test), through size-independent properties: (a) a training step is reproducible (same loss, gradients equal to f32
+    rounding: no float atomics anywhere on the path); (b) eval-mode batch independence: sample b of the B=32 forward equals the
+    B=1 forward of that sample (different kernel plans: fused cell / split-K at B=32, per-tap shapes at B=1); (c) the stateful
+    frame-by-frame rollout over all 20 frames equals the full-sequence forward."""
+    torch.manual_seed(91)
+    model = U.TemporalUNetDualView(1, 1, base_ch=64, use_skip_lstm=True).to(DEV)
+    data = U.SyntheticSequences(32, 20, 64, 64, seed=7, kind="blobs")
+    opt = U.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_grad_norm=None)
+    model.train()
+    runs = []
+    for _ in range(2):
+        loss, _ = U.train_step(model, opt, data.x, data.y, data.mask, True, clip_norm=None)
+        runs.append((float(loss), opt.flat.flat_g.detach().clone()))
+    d = rel_l2(runs[1][1].cpu(), runs[0][1].cpu())
+    print(f"[parity] full-size step twice: loss {runs[0][0]:.6f} / {runs[1][0]:.6f}, gradient rel-L2 {d:.2e}")
+    assert runs[0][0] == runs[1][0] and d <= 1e-6 and bool(torch.isfinite(runs[0][1]).all()) and float(runs[0][1].abs().max()) > 0
+    model.eval()
+    with torch.no_grad():
+        full, _ = model(data.x)
+        full = torch.stack(full, 1)
+        for b in (0, 17, 31):
+            one, _ = model(data.x[b:b + 1].contiguous())
+            e = max(per_t(torch.stack(one, 1).cpu(), full[b:b + 1].cpu()))
+            print(f"[parity] full-size eval: sample {b} alone vs inside the B=32 batch, worst per-timestep rel-L2 {e:.2e}")
+            assert e <= 2e-3
+        sp = U.StreamingPredictor(model, use_graph=True, warmup=1)
+        roll = sp.rollout(data.x[:4].contiguous())
+        e = max(per_t(roll.cpu(), full[:4].cpu()))
+        print(f"[parity] full-size eval: 20-frame stateful rollout (HIP graph) vs full-sequence forward, worst rel-L2 {e:.2e}")
+        assert e <= 2e-3
