@@ -301,7 +301,10 @@ def main():
                     traffic = json.load(open(tpath))["kernels"][dom]["hbm_bytes_per_launch"]
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": dom, "kernel_note": "epilogue family[tile shape the library picked]; rocprofv3 names: "
+                    "patch128x256 = igemm_fwd_kernel<epi, 2, nsrc>, pertap128x128 = <epi, 0, nsrc>, pertap64x256 = <epi, 1, nsrc>, "
+                    "ring64 = igemm_fwd_c64_kernel (epi 0 store, 1 fused ConvLSTM cell, 2 split-K slabs)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch", "traffic_source": TRAFFIC_NOTE if traffic is not None else None,
                     "launches": n, "timing": "HIP events, one serialised step (side stream off)",

@@ -121,6 +121,18 @@ def _timed_hbm(kind: str, nbytes: float, launch) -> None:
     PROFILE_HBM.append((kind, nbytes, e0, e1, ""))
 
 
+_SHAPE_NAMES = {0: "pertap128x128", 1: "pertap64x256", 2: "patch128x256", 3: "ring64"}
+
+
+def _kernel_kind(kind: str, d) -> str:
+    """Profile key of a forward-family launch: epilogue family + the kernel the library picks for this descriptor (the
+    rocprofv3 name is igemm_fwd_kernel<epilogue, shape, sources> / igemm_fwd_c64_kernel), so that bench.py's roofline leg
+    prices each KERNEL, not a mix of MFMA-bound 3x3 launches and HBM-bound 1x1 / 2x2 ones."""
+    if PROFILE is None:
+        return kind
+    return f"{kind}[{_SHAPE_NAMES.get(int(L.lib.uclstm_igemm_fwd_shape(C.byref(d))), '?')}]"
+
+
 def _timed(kind: str, flops: float, launch, note: str = "") -> None:
     if PROFILE is None:
         launch()
@@ -646,7 +658,7 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
     _log_shape(d)
     _same_act_dtype([sv.t for sv in srcs] + [wp] + [sg[0] for sg in segs], "igemm_fwd(store)")
     K = _k(wp)
-    _timed("igemm_fwd_store", flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
+    _timed(_kernel_kind("igemm_fwd_store", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}")
 
 
@@ -688,7 +700,7 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
     _log_shape(d)
     _same_act_dtype([sv.t for sv in srcs] + [wp], "igemm_fwd(atomic)")
     K = _k(wp)
-    _timed(kind, flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
+    _timed(_kernel_kind(kind, d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
            f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
 
 
@@ -720,7 +732,7 @@ def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor
     _log_shape(d)
     _same_act_dtype([h_prev, wp, h_out] + ([x] if x is not None else []) + ([gates_out] if gates_out is not None else []), "igemm_fwd(lstm)")
     K = _k(wp)
-    _timed("igemm_fwd_lstm", flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
+    _timed(_kernel_kind("igemm_fwd_lstm", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
            f"M={B * H * W} N={d.N} K={d.Ktot}")
 
 
