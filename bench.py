@@ -303,7 +303,8 @@ def main():
                     traffic = None
             roof = {"bound": "mfma", "kernel": dom, "kernel_note": "epilogue family[tile shape the library picked]; rocprofv3 names: "
                     "patch128x256 = igemm_fwd_kernel<epi, 2, nsrc>, pertap128x128 = <epi, 0, nsrc>, pertap64x256 = <epi, 1, nsrc>, "
-                    "ring64 = igemm_fwd_c64_kernel (epi 0 store, 1 fused ConvLSTM cell, 2 split-K slabs)",
+                    "ring64 = igemm_fwd_c64_kernel (epi 0 store, 1 fused ConvLSTM cell, 2 split-K slabs); igemm_wgrad[p3_256x256] = "
+                    "igemm_wgrad_p3_kernel, [p2_*] = igemm_wgrad_p2_kernel, [generic] = igemm_wgrad_kernel",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch", "traffic_source": TRAFFIC_NOTE if traffic is not None else None,

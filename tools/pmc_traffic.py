@@ -20,8 +20,13 @@ def family(name: str) -> str:
         return epi + "[" + {"0": "pertap128x128", "1": "pertap64x256", "2": "patch128x256"}[m.group(2)] + "]"
     if "igemm_fwd_c64" in name:        # the persistent 64-channel kernel serves UCLSTM_EPI_STORE launches
         return "igemm_fwd_store[ring64]"
+    if "igemm_wgrad_p3" in name:
+        return "igemm_wgrad[p3_256x256]"
+    m = re.search(r"igemm_wgrad_p2_kernel<(\d)", name)
+    if m:
+        return "igemm_wgrad[p2_64x256]" if m.group(1) == "1" else "igemm_wgrad[p2_128x128]"
     if "igemm_wgrad" in name:
-        return "igemm_wgrad"
+        return "igemm_wgrad[generic]"
     m = re.search(r"(\w+_kernel)", name)
     return m.group(1) if m else name[:40]
 

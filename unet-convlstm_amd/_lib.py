@@ -86,6 +86,7 @@ _PROTOS = {
     "uclstm_igemm_ksplit_used": [_I, _I],
     "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
     "uclstm_igemm_wgrad_splits": [C.POINTER(WgradDesc)],
+    "uclstm_igemm_wgrad_shape": [C.POINTER(WgradDesc)],
     "uclstm_pack_weights": [C.POINTER(PackDesc), _P, _P, _P],
     "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _I, _L, _P, _I, _P],
     "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],

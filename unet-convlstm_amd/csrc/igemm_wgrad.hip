@@ -790,7 +790,10 @@ bool wsrc_ok(const uclstm_src& s) {
 
 namespace {
 // plan_only: validate, choose kernel + splits and return the split count without launching (dwp may be null)
-int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
+// query: 0 = launch, 1 = return the pixel-range count (uclstm_igemm_wgrad_splits), 2 = return which kernel would run
+// (uclstm_igemm_wgrad_shape: 3 = 256 x 256 8-phase, 2 = 128 x 128, 1 = 64 x 256 for C_out <= 64, 0 = generic addressing)
+int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, int query) {
+    const bool plan_only = query != 0;
     if (!dp) return UCLSTM_E_BADARG;
     const uclstm_wgrad_desc& d = *dp;
     if (d.n_img <= 0 || d.H <= 0 || d.W <= 0) return UCLSTM_E_BADARG;
@@ -859,6 +862,7 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
     chunk = (chunk + TP - 1) / TP * TP;
     dv.chunk = chunk;
     dd.splits = (int)((dv.M + chunk - 1) / chunk);          // every split owns pixels (slab mode: every slab is written)
+    if (query == 2) return big ? 3 : (fast ? (wn == 1 ? 1 : 2) : 0);
     if (plan_only) return dd.splits;
     const int64_t nblk = (int64_t)dv.n_kt * dv.n_nt * dd.splits;
     if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
@@ -903,8 +907,11 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, bool plan_only) {
 }
 }  // namespace
 
-extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream) { return wgrad_run(d, stream, false); }
+extern "C" int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream) { return wgrad_run(d, stream, 0); }
 
 #ifndef UCLSTM_ACT_F16
-extern "C" int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d) { return wgrad_run(d, nullptr, true); }
+extern "C" int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d) { return wgrad_run(d, nullptr, 1); }
+#endif
+#ifndef UCLSTM_ACT_F16
+extern "C" int32_t uclstm_igemm_wgrad_shape(const uclstm_wgrad_desc* d) { return wgrad_run(d, nullptr, 2); }
 #endif
