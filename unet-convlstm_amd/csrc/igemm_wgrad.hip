@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const uclstm_wgrad_
 // instruction fills 8 rows of one plane, so all its lanes share one 64-column segment = one (tap, source): the
 // descriptor is wave-uniform.  32-byte granule g of row r sits at position g ^ ((r>>1)&3); two 128-byte rows share a
 // 256-byte bank row, so the eight row pieces of a transposing read (rows r..r+7) cover all 64 banks.
-// Two tile shapes: WN = 2: 128 panel rows x 128 K columns (waves 2x2);  WN = 1: 64 x 256 (waves 1x4) for C_out <= 64.
+// Tile shapes: WN = 2: 128 panel rows x 128 K columns (waves 2x2);  WN = 1: 64 x 256 (waves 1x4) for C_out <= 64;
+// WN = 3: 64 x 192 (waves 1x4, 48 columns = three MFMA column tiles each) for C_out <= 64 when 192 | Ktot -- the K = 576 / 1152
+// layers of the full-resolution level, where 256-column tiles are 25 % / 10 % padding.
 struct P2 {
     int lw, lh;            // log2 W, log2 H
     uint32_t ybytes;       // dY tensor bytes
@@ -262,9 +264,13 @@ constexpr uint32_t OOB = 0x80000000u;
 
 template <int WN>
 struct WShape {
-    static constexpr int WK = 4 / WN;
-    static constexpr int TN_ = 64 * WN, TC_ = 64 * WK;
-    static constexpr int NPL = WN + WK;                       // planes per stage (dY planes first)
+    static constexpr int WNR = WN == 2 ? 2 : 1;               // waves (= dY planes) along panel rows
+    static constexpr int WK = 4 / WNR;                        // waves along K columns
+    static constexpr int XP = WN == 3 ? 3 : WK;               // X planes (64 K columns each) per stage
+    static constexpr int NB = WN == 3 ? 3 : 4;                // MFMA column tiles (16 columns) per wave
+    static constexpr int WCOLS = 16 * NB;                     // K columns per wave
+    static constexpr int TN_ = 64 * WNR, TC_ = 64 * XP;
+    static constexpr int NPL = WNR + XP;                      // planes per stage (dY planes first)
     static constexpr int STAGE = NPL * PLANE;                 // 32 KiB / 40 KiB
     static constexpr int SMEM = 2 * STAGE;
     static constexpr int NI = 2 * NPL;                        // DMA instructions per wave per stage (8 per plane / 4 waves)
@@ -331,18 +337,18 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
     const int kseg = dv.kseg0 + dv.kseg1;
 
     uint32_t voff[SH::NI];            // loop-invariant byte offsets (dY planes, then X planes)
-    uint32_t kxj[2 * WK], kyj[2 * WK];
-    int xsrc[WK];                     // wave-uniform source of each X plane
+    uint32_t kxj[2 * SH::XP], kyj[2 * SH::XP];
+    int xsrc[SH::XP];                 // wave-uniform source of each X plane
 #pragma unroll
     for (int j = 0; j < SH::NI; ++j) {
         const int pl = j >> 1;
         const int r = 8 * (4 * (j & 1) + wave) + lrow;        // pixel row of the stage
-        if (pl < WN) {
+        if (pl < SH::WNR) {
             const int ny = n0 + pl * 64 + sc * 8;
             const bool yok = ny < d.N && ny >= G.n_begin && ny < G.n_end;
             voff[j] = yok ? (uint32_t)(2 * (r * G.C + G.c_off + (ny - G.n_begin))) : OOB;
         } else {
-            const int xp = pl - WN;
+            const int xp = pl - SH::WNR;
             const int k0 = kbase + xp * 64;                   // first column of the plane: one (tap, source)
             const int xtap = (int)fdiv((uint32_t)k0, dv.dPerTap);
             const int kr = k0 - xtap * kseg;
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
             if ((j & 1) == 0) xsrc[xp] = xs_;
             voff[j] = xok ? (uint32_t)(2 * (r * S.C + (ddy * S.Ws + ddx) * S.C + xc) + (int)p2.xbias[xs_]) : OOB;
             // bad column <=> (mb & (W-1)) == kxj ; bad row <=> ((mb >> lw) & (H-1)) == kyj   (0xffffffff: never)
-            const int jj = j - 2 * WN;
+            const int jj = j - 2 * SH::WNR;
             if (badx < 0) kxj[jj] = 0xffffffffu;
             else if (d.W >= 64) kxj[jj] = (uint32_t)(badx - r);        // equal only if a non-negative multiple of 64
             else kxj[jj] = ((r & Wm) == badx) ? 0u : 0xffffffffu;
@@ -367,11 +373,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
     }
     const uint32_t ystep = (uint32_t)(2 * G.C), x0step = (uint32_t)(2 * d.src[0].C), x1step = (uint32_t)(2 * d.src[NSRC - 1].C);
 
-    f32x4 acc[4][4];
+    constexpr int NB = SH::NB;
+    f32x4 acc[4][NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint32_t mb = (uint32_t)m_begin;      // first pixel of the NEXT stage to load (wave-uniform)
     auto issue_loads = [&](int buf) {
@@ -382,10 +389,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
 #pragma unroll
         for (int j = 0; j < SH::NI; ++j) {
             lds_ptr dst = (lds_ptr)(St + (j >> 1) * PLANE + (4 * (j & 1) + wave) * 1024);
-            if (j < 2 * WN) {
+            if (j < 2 * SH::WNR) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, dst, 16, voff[j], ysoff, 0, 0);
             } else {
-                const int jj = j - 2 * WN;
+                const int jj = j - 2 * SH::WNR;
                 const bool ok = (sx != kxj[jj]) & (sy != kyj[jj]);
                 const uint32_t off = ok ? voff[j] : OOB;
                 if (NSRC == 1 || xsrc[jj >> 1] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx0, dst, 16, off, x0soff, 0, 0);
@@ -400,20 +407,27 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
     int goff[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) goff[a] = trow * 128 + ((a ^ ((trow >> 1) & 3)) << 5) + (l15 & 3) * 8;
+    // this wave's K-column tiles: tile ct = wk * NB + b (16 columns each) lives in X plane ct / 4, granule ct % 4
+    int xoff[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ct = wk * NB + b;
+        xoff[b] = (SH::WNR + (ct >> 2)) * PLANE + trow * 128 + (((ct & 3) ^ ((trow >> 1) & 3)) << 5) + (l15 & 3) * 8;
+    }
     auto compute = [&](int buf) {
-        const unsigned char* Y = smem + buf * SH::STAGE + wc * PLANE;
-        const unsigned char* X = smem + buf * SH::STAGE + (WN + wk) * PLANE;
+        const unsigned char* St = smem + buf * SH::STAGE;
+        const unsigned char* Y = St + wc * PLANE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            act16x8 yf[4], xf[4];
+            act16x8 yf[4], xf[NB];
 #pragma unroll
             for (int a = 0; a < 4; ++a) yf[a] = tr_frag128(Y + ks * 32 * 128 + goff[a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xf[b] = tr_frag128(X + ks * 32 * 128 + goff[b]);
+            for (int b = 0; b < NB; ++b) xf[b] = tr_frag128(St + ks * 32 * 128 + xoff[b]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NB; ++b)
                     acc[a][b] = UCLSTM_MFMA_16x16x32(yf[a], xf[b], acc[a][b], 0, 0, 0);
         }
     };
@@ -431,27 +445,24 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_p2_kernel(const uclstm_wgr
     constexpr int AP = TCc + 4;
     float* At = (float*)smem;                // [64 panel rows][AP]
 #pragma unroll
-    for (int half = 0; half < WN; ++half) {
+    for (int half = 0; half < SH::WNR; ++half) {
         if (wc == half) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) At[(a * 16 + lq * 4 + r) * AP + wk * 64 + b * 16 + l15] = acc[a][b][r];
+                    for (int r = 0; r < 4; ++r) At[(a * 16 + lq * 4 + r) * AP + wk * SH::WCOLS + b * 16 + l15] = acc[a][b][r];
         }
         __syncthreads();
-        const int col = tid % TCc;
-        const int k = kbase + col;
-        if (k < d.Ktot) {
-            for (int pr = tid / TCc; pr < 64; pr += 256 / TCc) {
-                const int n = n0 + half * 64 + pr;
-                if (n < d.N)
-                    {
-                    float* dst = d.dwp + (long)sp * d.slab + (long)n * d.Ktot + k;
-                    if (d.slab > 0) *dst = At[pr * AP + col];        // this pixel range's own slab (added up by the unpack kernel)
-                    else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+        for (int idx = tid; idx < 64 * TCc; idx += 256) {          // consecutive threads = consecutive K columns of one panel row
+            const int pr = idx / TCc, col = idx - pr * TCc;
+            const int k = kbase + col;
+            const int n = n0 + half * 64 + pr;
+            if (k < d.Ktot && n < d.N) {
+                float* dst = d.dwp + (long)sp * d.slab + (long)n * d.Ktot + k;
+                if (d.slab > 0) *dst = At[pr * AP + col];        // this pixel range's own slab (added up by the unpack kernel)
+                else __hip_atomic_fetch_add(dst, At[pr * AP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -848,8 +859,9 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, int query) {
     }
     static const bool no_p3 = [] { const char* e = getenv("UCLSTM_WGRAD_NO256"); return e && e[0] == '1'; }();
     const bool big = fast && !no_p3 && d.N >= 256;              // 256 x 256 tile, 8-phase pipeline
-    const int wn = (fast && d.N <= 64) ? 1 : 2;
-    const int tn = big ? 256 : 64 * wn, tc = big ? 256 : 256 / wn;
+    static const bool no_192 = [] { const char* e = getenv("UCLSTM_WGRAD_NO192"); return e && e[0] == '1'; }();
+    const int wn = (fast && d.N <= 64) ? ((!no_192 && d.Ktot % 192 == 0) ? 3 : 1) : 2;      // 3: 64 x 192 tile (no padding at K = 576 / 1152)
+    const int tn = big ? 256 : (wn == 2 ? 128 : 64), tc = big ? 256 : (wn == 2 ? 128 : (wn == 3 ? 192 : 256));
     dv.n_kt = (d.Ktot + tc - 1) / tc;
     dv.n_nt = (d.N + tn - 1) / tn;
     dv.kt_per_tap = (fast && ((dv.kseg0 + dv.kseg1) % tc) == 0) ? (dv.kseg0 + dv.kseg1) / tc : 0;
@@ -862,7 +874,7 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, int query) {
     chunk = (chunk + TP - 1) / TP * TP;
     dv.chunk = chunk;
     dd.splits = (int)((dv.M + chunk - 1) / chunk);          // every split owns pixels (slab mode: every slab is written)
-    if (query == 2) return big ? 3 : (fast ? (wn == 1 ? 1 : 2) : 0);
+    if (query == 2) return big ? 3 : (fast ? (wn == 2 ? 2 : 1) : 0);
     if (plan_only) return dd.splits;
     const int64_t nblk = (int64_t)dv.n_kt * dv.n_nt * dd.splits;
     if (nblk <= 0 || nblk > 0x7fffffff) return UCLSTM_E_BADARG;
@@ -891,6 +903,7 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, int query) {
     }
     if (fast) {
         if (wn == 1) return d.nsrc == 1 ? launch_p2<1, 1>(dd, dv, p2, nblk, st) : launch_p2<1, 2>(dd, dv, p2, nblk, st);
+        if (wn == 3) return d.nsrc == 1 ? launch_p2<3, 1>(dd, dv, p2, nblk, st) : launch_p2<3, 2>(dd, dv, p2, nblk, st);
         return d.nsrc == 1 ? launch_p2<2, 1>(dd, dv, p2, nblk, st) : launch_p2<2, 2>(dd, dv, p2, nblk, st);
     }
     static bool attr_done = false;
