@@ -152,8 +152,9 @@ int32_t uclstm_igemm_wgrad(const uclstm_wgrad_desc* d, void* stream);
 /* Pixel ranges (= slabs in slab mode) the launch above will use for this descriptor; d->dwp may be NULL.  Call it with
  * splits = 0, size dwp as [result][N][Ktot], then launch with splits = result. */
 int32_t uclstm_igemm_wgrad_splits(const uclstm_wgrad_desc* d);
-/* Which kernel uclstm_igemm_wgrad would run for this descriptor (nothing is launched): 3 = 256 x 256 tile, 8-phase pipeline
- * (C_out >= 256), 2 = 128 x 128 tile, 1 = 64 x 256 tile (C_out <= 64), 0 = generic addressing (non-power-of-two images,
+/* Which kernel uclstm_igemm_wgrad would run for this descriptor (nothing is launched): 4 = ring-staged kernel of the 64-channel
+ * full-resolution layers (slab mode only), 3 = 256 x 256 tile, 8-phase pipeline (C_out >= 256), 2 = 128 x 128 tile,
+ * 1 = 64 x 256 / 64 x 192 tile (C_out <= 64), 0 = generic addressing (non-power-of-two images,
  * ConvTranspose, offset sources, kernels wider than 3x3).  Used by bench.py to price each kernel separately. */
 int32_t uclstm_igemm_wgrad_shape(const uclstm_wgrad_desc* d);
 

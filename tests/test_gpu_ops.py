@@ -12,6 +12,7 @@ flipped elements costs sqrt(p) in rel-L2 (p ~ 0.3-1 % per ReLU stage).  Stated b
 gradients <= 8e-2, input gradients through two ReLU stages <= 1.5e-1; the single-stage operator test
 above (same rounded operands, so the masks coincide) holds 1.5e-2.
 """
+import ctypes
 import math
 import os
 
@@ -320,6 +321,12 @@ def test_colsum(pixels, Cp):
     (2, 64, 64, 256, 16, 16),
     (2, 64, 0, 512, 64, 64),
     (6, 72, 200, 264, 8, 8),
+    # 64 -> 64 channels on images a multiple of 64 wide: the ring-staged kernel (uclstm_igemm_wgrad_shape == 4) -- one strip,
+    # two strips with real halo columns, two sources, tile ranges that cross image boundaries (more tiles than blocks)
+    (3, 64, 0, 64, 8, 64),
+    (2, 64, 0, 64, 12, 128),
+    (2, 64, 64, 64, 8, 128),
+    (25, 64, 0, 64, 32, 128),
 ])
 def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
     torch.manual_seed(3)
@@ -336,7 +343,17 @@ def test_conv3x3_wgrad(N, C0, C1, Co, H, W):
         cv, cp = [C0, C1], [cpad(C0), cpad(C1)]
     pd = ops.conv_pack_desc(Co, Ci, cv, cp)
     dyn = to_nhwc(dy)
+    wd = U._lib.WgradDesc()
+    wd.n_img, wd.H, wd.W, wd.ktap, wd.scale, wd.pad, wd.nsrc = N, H, W, 3, 1, 1, len(srcs)
+    for i, sv in enumerate(srcs):
+        sv.fill(wd.src[i])
+    wd.N, wd.Ktot, wd.nseg, wd.slab = pd.N, pd.Ktot, 1, pd.N * pd.Ktot
+    ops._fill_seg(wd.seg[0], dyn, 0, cpad(Co), 0, 1, 0, 0)
+    shape = int(U._lib.lib.uclstm_igemm_wgrad_shape(ctypes.byref(wd)))
+    ring = C0 == 64 and Co == 64 and C1 in (0, 64) and W % 64 == 0 and H % 4 == 0
+    assert (shape == 4) == ring, f"weight-gradient kernel {shape} for this case"
     dwp = ops.igemm_wgrad(srcs, [(dyn, 0, cpad(Co), 0, 1, 0, 0)], pd.N, pd.Ktot, (H, W), N, ktap=3, pad=1)
+    assert bool(torch.isfinite(dwp).all())
     w = torch.zeros(Co, Ci, 3, 3)
     got = ops.unpack_wgrad(pd, dwp, w.to(DEV)).cpu()
     wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)

@@ -20,6 +20,8 @@ def family(name: str) -> str:
         return epi + "[" + {"0": "pertap128x128", "1": "pertap64x256", "2": "patch128x256"}[m.group(2)] + "]"
     if "igemm_fwd_c64" in name:        # the persistent 64-channel kernel serves UCLSTM_EPI_STORE launches
         return "igemm_fwd_store[ring64]"
+    if "igemm_wgrad_c64" in name:
+        return "igemm_wgrad[ring64]"
     if "igemm_wgrad_p3" in name:
         return "igemm_wgrad[p3_256x256]"
     m = re.search(r"igemm_wgrad_p2_kernel<(\d)", name)

@@ -781,6 +781,221 @@ int auto_splits(int64_t tiles, int64_t stages, bool slabs, int64_t panel_elems) 
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ring-staged weight gradient of the 64-channel full-resolution layers (C_out = 64, sources of 64 channels, 3x3 / pad 1,
+// images a multiple of 64 wide and of 4 high): the p2 kernel above re-stages every activation plane once per tap and the dY
+// plane once per K tile -- 48 flop per staged byte, staging-bound at ~0.6 PFLOP/s.  Here, as in igemm_fwd_c64_kernel, a
+// persistent block walks 4-row x 64-column tiles of one image strip; the activation rows live in a ring of ten image rows
+// (each staged ONCE, halo columns included), the dY tile (4 planes of [64 px][64 ch]) is double-buffered, and all nine taps are
+// SHIFTED transposing reads of the ring: ~295 flop per staged byte.
+//   out[n][tap][c] += sum_p dY[p][n] * x[p + tap][c]:  MFMA A = dY^T (16 n x 32 pixels), B = x (32 pixels x 16 c), both
+//   produced by ds_read_b64_tr_b16 from pixel-major rows (same k-permutation on both, see the top of the file).
+//   Wave w owns input-channel tile w (16 channels) x all 9 taps x all 4 n tiles: 36 accumulator tiles (144 VGPRs); per
+//   (image row, 32-pixel half) it reads 4 dY fragments + 9 shifted x fragments for 36 MFMAs.
+//   Ring rows are 72 LDS rows apart (66 used: 64 pixels + 2 halo columns): a multiple of 8, so the granule swizzle
+//   g ^ ((row >> 1) & 3) does not depend on the slot and a tap shift of dx rows stays conflict-free (any 8 consecutive rows
+//   cover all 64 banks).
+// One launch per source; every block accumulates its whole tile range in registers and stores ONE slab (grid = slab count).
+constexpr int WR_PITCH = 72 * 128;                 // bytes between ring slots
+constexpr int WR_SLOTS = 10;
+constexpr int WR_RING = WR_SLOTS * WR_PITCH;       // 92160
+constexpr int WR_DZ = 4 * PLANE;                   // one dY tile: 4 image rows x [64 px][64 ch]
+constexpr int WR_SMEM = WR_RING + 2 * WR_DZ;       // 157696
+
+__global__ __launch_bounds__(256, 1) void igemm_wgrad_c64_kernel(const uclstm_wgrad_desc d, const int src, const int kcol0, const int per_tap,
+                                                                  const int tiles_total, const int tiles_per_block, const uint32_t xbytes,
+                                                                  const uint32_t ybytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ring = smem;
+    unsigned char* Dz = smem + WR_RING;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+    const int H = d.H, W = d.W;
+    const int strips = W >> 6;
+    const int n_seq = d.n_img * strips;
+    const int tiles_per_seq = H >> 2;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(tiles_total, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+
+    const uclstm_seg G = d.seg[0];
+    const uclstm_src S = d.src[src];
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)G.ptr, 0, ybytes, 0x00020000);
+
+    // zero the halo columns (ring positions 0 and 65 of every slot) once: permanent when the image is one strip wide
+    if (tid < WR_SLOTS * 2 * 8) {
+        const int sl = tid >> 4, side = (tid >> 3) & 1, ch = tid & 7;
+        *(uint4*)(Ring + sl * WR_PITCH + side * 65 * 128 + ch * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- staging roles.  A DMA instruction of a wave covers 8 LDS rows x 128 B: lane = (row lane>>3, 16-byte position lane&7);
+    // position cp of LDS row r holds source chunk 2*((cp>>1) ^ ((r>>1)&3)) + (cp&1).
+    const int lrow = lane >> 3, cp = lane & 7;
+    // activation row: pixels 8*(wave + 4i) + lrow, i = 0, 1, at ring positions pixel + 1
+    uint32_t xvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = 8 * (wave + 4 * i) + lrow;
+        const int r = px + 1;
+        const int sc = 2 * ((cp >> 1) ^ ((r >> 1) & 3)) + (cp & 1);
+        xvoff[i] = (uint32_t)(2 * (px * 64 + sc * 8));
+    }
+    // the DMA of instruction i lands at LDS rows 8*(wave+4i)+1 .. +8 of the slot: NOT 8-row aligned, so it is issued per row
+    // piece through the lane's own address (M0-relative LDS addressing writes lane l at base + 16*l): base = row (8*(wave+4i)+1)
+    // halo pixels (strips > 1): waves 0 / 1, lanes 0..7 -> ring position 0 / 65
+    const int hpos = wave == 0 ? 0 : 65;
+    const uint32_t halo_voff = (uint32_t)(2 * ((2 * (((lane & 7) >> 1) ^ ((hpos >> 1) & 3)) + (lane & 1)) * 8));
+    // dY plane rows: instruction j of wave w covers pixel rows 8*(w + 4*(j&1)) + lrow of plane j>>1
+    uint32_t yvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = 8 * (wave + 4 * i) + lrow;
+        const int sc = 2 * ((cp >> 1) ^ ((px >> 1) & 3)) + (cp & 1);
+        yvoff[i] = (uint32_t)(2 * (px * G.C + G.c_off + sc * 8));
+    }
+
+    int lk = 0, ly = 0, lslot = 0, loaded = -2, limg = 0, lstrip = 0;
+#define WR_ISSUE_NEXT_ROW()                                                                                                 \
+    {                                                                                                                       \
+        const bool zero_ = ly == H || lk < 0 || lk >= n_seq;                                                                \
+        const uint32_t soff_ = zero_ ? 0u : (uint32_t)((limg * H + ly) * W + lstrip * 64) * 128u;                           \
+        unsigned char* dst_ = Ring + lslot * WR_PITCH + 128;                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + wave * 1024), 16, zero_ ? OOB : xvoff[0], soff_, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst_ + (wave + 4) * 1024), 16, zero_ ? OOB : xvoff[1], soff_, 0, 0);  \
+        if (strips > 1 && wave < 2) {                                                                                       \
+            const bool ok_ = !zero_ && (wave == 0 ? lstrip > 0 : lstrip < strips - 1);                                      \
+            const uint32_t hs_ = ok_ ? (wave == 0 ? soff_ - 128u : soff_ + 64u * 128u) : 0u;                                \
+            if (lane < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(Ring + lslot * WR_PITCH + hpos * 128), 16, \
+                                                                   ok_ ? halo_voff : OOB, hs_, 0, 0);                       \
+        }                                                                                                                   \
+        ++loaded;                                                                                                           \
+        lslot = lslot == WR_SLOTS - 1 ? 0 : lslot + 1;                                                                      \
+        if (ly == H) {                                                                                                      \
+            ly = 0;                                                                                                         \
+            ++lk;                                                                                                           \
+            if (++lstrip == strips) { lstrip = 0; ++limg; }                                                                 \
+        } else {                                                                                                            \
+            ++ly;                                                                                                           \
+        }                                                                                                                   \
+    }
+    // the dY tile of tile (sequence k_, row group tr_) into buffer b_
+#define WR_ISSUE_DZ(k_, tr_, b_)                                                                                            \
+    {                                                                                                                       \
+        const int img_ = (k_) / strips, st_ = (k_) - img_ * strips;                                                         \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 4; ++pl_) {                                                               \
+            const uint32_t so_ = (uint32_t)((img_ * H + 4 * (tr_) + pl_) * W + st_ * 64) * (uint32_t)(2 * G.C);             \
+            unsigned char* dp_ = Dz + (b_) * WR_DZ + pl_ * PLANE;                                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (lds_ptr)(dp_ + wave * 1024), 16, yvoff[0], so_, 0, 0);           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (lds_ptr)(dp_ + (wave + 4) * 1024), 16, yvoff[1], so_, 0, 0);     \
+        }                                                                                                                   \
+    }
+
+    // ---- fragment read offsets: pixel row trow of a 16-row group, 8 bytes (4 channels) at (l15 & 3)
+    const int trow = 4 * lq + (l15 >> 2);
+    int yoff[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) yoff[a] = trow * 128 + ((a ^ ((trow >> 1) & 3)) << 5) + (l15 & 3) * 8;
+    int xoff[3];                 // this wave's 16-channel granule, window shifted by dx rows (ring position = pixel + dx)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int r = dx + trow;
+        xoff[dx] = r * 128 + ((wave ^ ((r >> 1) & 3)) << 5) + (l15 & 3) * 8;
+    }
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int k = t_begin / tiles_per_seq;
+    int tr = t_begin - k * tiles_per_seq;
+    WR_ISSUE_DZ(k, tr, 0)
+    for (int tt = t_begin; tt < t_end; ++tt) {
+        const int v0 = k * (H + 1) + 4 * tr;
+        if (tt == t_begin) {      // cursor at virtual row v0 - 1
+            const int v = v0 - 1;
+            if (v < 0) { lk = -1; ly = H; limg = 0; lstrip = -1; } else { lk = v / (H + 1); ly = v - lk * (H + 1); limg = lk / strips; lstrip = lk - limg * strips; }
+            lslot = (v + 1) % WR_SLOTS;
+            loaded = v - 1;
+        }
+        while (loaded < v0 + 4) WR_ISSUE_NEXT_ROW()
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int k1 = k, tr1 = tr + 1;
+        if (tr1 == tiles_per_seq) { tr1 = 0; ++k1; }
+        if (tt + 1 < t_end) {          // next tile: its dY tile into the other buffer, up to four new rows into the free slots
+            WR_ISSUE_DZ(k1, tr1, (tt + 1 - t_begin) & 1)
+            const int upto = min(k1 * (H + 1) + 4 * tr1 + 4, loaded + 4);
+            while (loaded < upto) WR_ISSUE_NEXT_ROW()
+        }
+        const unsigned char* Y = Dz + ((tt - t_begin) & 1) * WR_DZ;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const unsigned char* rowp[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) rowp[dy] = Ring + ((v0 + rr + dy) % WR_SLOTS) * WR_PITCH;      // virtual row v0 + rr + dy - 1
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                act16x8 yf[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) yf[a] = tr_frag128(Y + rr * PLANE + ks * 32 * 128 + yoff[a]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const act16x8 xf = tr_frag128(rowp[t / 3] + ks * 32 * 128 + xoff[t % 3]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[t][a] = UCLSTM_MFMA_16x16x32(yf[a], xf, acc[t][a], 0, 0, 0);
+                }
+            }
+        }
+        k = k1;
+        tr = tr1;
+    }
+    // ---- one slab per block: dWp[n][tap * per_tap + kcol0 + 16*wave + l15], n = a*16 + lq*4 + r
+    float* out = d.dwp + (long)blockIdx.x * d.slab + kcol0 + wave * 16 + l15;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = a * 16 + lq * 4 + r;
+                if (n < d.N) out[(long)n * d.Ktot + t * per_tap] = acc[t][a][r];
+            }
+#endif
+}
+#undef WR_ISSUE_NEXT_ROW
+#undef WR_ISSUE_DZ
+
+// launch conditions of igemm_wgrad_c64_kernel
+inline bool wgrad_c64_ok(const uclstm_wgrad_desc& d, bool plain) {
+    static const bool off = [] { const char* e = getenv("UCLSTM_WGRAD_RING"); return e && e[0] == '0'; }();
+    if (off || !plain || d.ktap != 3 || d.pad != 1 || d.nseg != 1 || d.slab <= 0) return false;
+    if (d.N > 64 || d.N <= 0 || (d.W & 63) || (d.H & 3)) return false;
+    const uclstm_seg& g = d.seg[0];
+    if (g.C != 64 || g.c_off != 0 || g.n_begin != 0) return false;
+    for (int s = 0; s < d.nsrc; ++s)
+        if (d.src[s].C != 64) return false;
+    if (d.Ktot != 9 * 64 * d.nsrc) return false;
+    if ((int64_t)d.n_img * d.H * d.W * 128 >= ((int64_t)1 << 31) - (1 << 22)) return false;
+    if ((int64_t)d.n_img * (d.W / 64) * (d.H + 1) >= ((int64_t)1 << 30)) return false;
+    return true;
+}
+inline int wgrad_c64_grid(const uclstm_wgrad_desc& d, int& per) {
+    const int tiles_total = d.n_img * (d.W / 64) * (d.H / 4);
+    const int cap = d.overlapped ? 128 : 256;
+    const int blocks = tiles_total < cap ? tiles_total : cap;
+    per = (tiles_total + blocks - 1) / blocks;
+    return (tiles_total + per - 1) / per;
+}
+
 template <int WN, int NSRC>
 int32_t launch_p2(const uclstm_wgrad_desc& d, const WDerived& dv, const P2& p2, int64_t nblk, hipStream_t st) {
     static bool attr_done = false;
@@ -831,6 +1046,26 @@ int32_t wgrad_run(const uclstm_wgrad_desc* dp, void* stream, int query) {
     dv.kseg1 = d.nsrc > 1 ? round_up32(d.src[1].C, 64) : 0;
     const int taps = d.ktap * d.ktap;
     if (d.Ktot != taps * (dv.kseg0 + dv.kseg1)) return UCLSTM_E_BADARG;
+    if (wgrad_c64_ok(d, plain)) {            // ring-staged kernel of the 64-channel full-resolution layers: grid = slab count
+        int per = 0;
+        const int grid = wgrad_c64_grid(d, per);
+        if (query == 2) return 4;
+        if (query == 1) return grid;
+        if (d.splits != grid) return UCLSTM_E_BADARG;
+        static bool attr_r = false;
+        if (!attr_r) {
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WR_SMEM);
+            attr_r = true;
+        }
+        const int tiles_total = d.n_img * (d.W / 64) * (d.H / 4);
+        const uint32_t ybytes = (uint32_t)((int64_t)d.n_img * d.H * d.W * d.seg[0].C * 2);
+        for (int sidx = 0; sidx < d.nsrc; ++sidx) {
+            const uint32_t xbytes = (uint32_t)((int64_t)d.n_img * d.H * d.W * 128);
+            UCLSTM_LAUNCH(igemm_wgrad_c64_kernel, dim3(grid), dim3(256), WR_SMEM, (hipStream_t)stream, d, sidx, sidx * 64, 64 * d.nsrc, tiles_total,
+                          per, xbytes, ybytes);
+        }
+        return UCLSTM_OK;
+    }
     dv.M = (long)d.n_img * d.H * d.W;
     if (dv.M >= ((long)1 << 31) - 4096) return UCLSTM_E_BADARG;
     dv.dHW = make_fastdiv((uint32_t)(d.H * d.W));

@@ -775,7 +775,7 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
         flops = 2.0 * d.n_img * out_hw[0] * out_hw[1] * N * taps * sum(s.t.shape[3] for s in srcs)
         kind = "igemm_wgrad"
         if PROFILE is not None:          # rocprofv3 names: igemm_wgrad_p3_kernel / igemm_wgrad_p2_kernel<1 or 2, nsrc> / igemm_wgrad_kernel
-            kind += "[" + {3: "p3_256x256", 2: "p2_128x128", 1: "p2_64x256", 0: "generic"}.get(int(L.lib.uclstm_igemm_wgrad_shape(C.byref(d))), "?") + "]"
+            kind += "[" + {4: "ring64", 3: "p3_256x256", 2: "p2_128x128", 1: "p2_64x256", 0: "generic"}.get(int(L.lib.uclstm_igemm_wgrad_shape(C.byref(d))), "?") + "]"
         _timed(kind, flops, lambda d=d: L.check(K.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
                f"M={d.n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
     return dwp
