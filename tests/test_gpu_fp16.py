@@ -180,3 +180,30 @@ def test_fp16_training_steps_with_dynamic_loss_scaling_learn():
     assert float(opt.scale_state[2]) >= 6             # successful steps were taken afterwards
     assert all(v == v for v in losses) and losses[-1] < losses[0]
     assert not torch.equal(opt.flat.flat_p, p_before) and bool(torch.isfinite(opt.flat.flat_p).all())
+
+
+@pytest.mark.parametrize("N,C0,C1,Co,H,W", [(2, 64, 0, 64, 8, 128), (2, 64, 64, 64, 4, 64), (2, 64, 0, 256, 16, 16), (2, 64, 0, 128, 32, 32)])
+def test_weight_gradient_kernels_fp16(N, C0, C1, Co, H, W):
+    """The fp16 twins of the weight-gradient kernels (ring-staged 64-channel kernel, 8-phase 256x256, 128x128) against
+    F.conv2d's weight gradient on the same binary16-rounded operands."""
+    import ctypes
+    torch.manual_seed(81)
+    h = lambda t: t.half().float()
+    x0, dy = h(torch.randn(N, C0, H, W)), h(torch.randn(N, Co, H, W))
+    with ops.compute_dtype(torch.float16):
+        srcs = [ops.SrcView(ops.ToNHWC.apply(x0.to(DEV)))]
+        xin, cv = x0, [C0]
+        if C1:
+            x1 = h(torch.randn(N, C1, H, W))
+            srcs.append(ops.SrcView(ops.ToNHWC.apply(x1.to(DEV))))
+            xin, cv = torch.cat((x0, x1), 1), [C0, C1]
+        dyn = ops.ToNHWC.apply(dy.to(DEV))
+    assert dyn.dtype == torch.float16
+    pd = ops.conv_pack_desc(Co, C0 + C1, cv, cv)
+    dwp = ops.igemm_wgrad(srcs, [(dyn, 0, Co, 0, 1, 0, 0)], pd.N, pd.Ktot, (H, W), N, ktap=3, pad=1)
+    got = ops.unpack_wgrad(pd, dwp, torch.zeros(Co, C0 + C1, 3, 3, device=DEV)).cpu()
+    wr = torch.zeros(Co, C0 + C1, 3, 3, requires_grad=True)
+    (F.conv2d(xin, wr, None, padding=1) * dy).sum().backward()
+    e = rel_l2(got, wr.grad)
+    print(f"[parity] fp16 weight gradient N={N} C={C0}+{C1} -> {Co} {H}x{W}: rel-L2 {e:.2e}")
+    assert e <= 2e-6
