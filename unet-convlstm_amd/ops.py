@@ -454,6 +454,7 @@ def _slabs_of(dwp: torch.Tensor) -> Tuple[int, int]:
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+PARAM_GRADS_ON_SIDE = os.environ.get("UCLSTM_PARAM_GRADS_ON_SIDE", "1") != "0"   # BatchNorm parameter gradients on the weight-gradient stream
 HOIST_X = os.environ.get("UCLSTM_HOIST_X", "0") == "1"               # x half of the ConvLSTM gate conv as one GEMM over all T (off: measured slower)
 POOL_SKIP = os.environ.get("UCLSTM_POOL_SKIP", "1") != "0"            # skip-connection gradient added inside max-pool backward
 DIRECT_GRADS = os.environ.get("UCLSTM_DIRECT_GRADS", "1") != "0"     # small parameter gradients written by the backward kernels
@@ -798,6 +799,8 @@ def bias_grad_from_colsum(a: torch.Tensor, bias: Optional[torch.Tensor], valid: 
         return None
     g = direct_grad(bias)
     if g is not None and g.numel() == a.shape[-1] == valid:
+        # (moving this HBM-bound pass to the weight-gradient stream was measured: no gain, unlike the tiny BatchNorm
+        # parameter-gradient kernels below)
         colsum(a, into=g.view(-1))
         grad_written(bias)
         return None
@@ -1012,11 +1015,24 @@ class ConvBNReLU(torch.autograd.Function):
         bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
         g_gamma, g_beta = direct_grad(gamma), direct_grad(beta)
         if g_gamma is not None and g_beta is not None:
-            # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates)
-            L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
+            # one kernel accumulates straight into the attached gradient buffers (instead of sum + 2 copies + 2 accumulates).
+            # Nothing in the backward pass waits for it: with the weight-gradient stream in use it goes there (18 small
+            # dependent launches off the main stream; joined with the weight gradients at the end of backward).
+            if ASYNC_WGRAD and PARAM_GRADS_ON_SIDE:
+                main, side = torch.cuda.current_stream(dev), side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()),
+                            "bn_bwd_param_grads")
+                    sums.record_stream(side)
+                    grad_written(gamma)
+                    grad_written(beta)
+                _schedule_join(dev)
+            else:
+                L.check(L.lib.uclstm_bn_bwd_param_grads(_p(sums), groups, Cop, Co, _p(g_gamma), _p(g_beta), 1, _stream()), "bn_bwd_param_grads")
+                grad_written(gamma)
+                grad_written(beta)
             dgamma = dbeta = None
-            grad_written(gamma)
-            grad_written(beta)
             dbias = None
             if has_bias:
                 g_bias = direct_grad(bias)
