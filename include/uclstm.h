@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 8
+#define UCLSTM_ABI_VERSION 9
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -205,6 +205,15 @@ int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tiles_per_group
                            int64_t count_per_group, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps,
                            float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* The same split in two, so that the sequential part leaves the critical path: uclstm_bn_stats_fwd is ONE launch that reduces the
+ * partial sums and writes scale / shift / mean / rstd (`stats` is consumed as above); uclstm_bn_running_stats applies the in-order
+ * momentum steps to the running statistics from what that launch left in `stats` -- nothing in the forward or backward pass waits
+ * for it (the host layer runs it on its second stream). */
+int32_t uclstm_bn_stats_fwd(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C, int64_t count_per_group,
+                            const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                            void* stream);
+int32_t uclstm_bn_running_stats(const float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
+                                int64_t count_per_group, float* running_mean, float* running_var, float momentum, void* stream);
 /* a = relu(z*scale[g] + shift[g]),  g = pixel / pixels_per_group;  z, a bf16 [pixels][Cp]. */
 int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift,
                              int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);

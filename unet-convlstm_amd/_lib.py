@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -91,6 +91,8 @@ _PROTOS = {
     "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _I, _L, _P, _I, _P],
     "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],
     "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    "uclstm_bn_stats_fwd": [_P, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _P, _P, _P],
+    "uclstm_bn_running_stats": [_P, _I, _I, _I, _I, _L, _P, _P, _F, _P],
     "uclstm_bn_apply_relu": [_P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_reduce_rows": [_L, _L],
     "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],

@@ -75,6 +75,69 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(float* __restrict__ sta
     }
 }
 
+// Training-mode forward, critical part in ONE launch: the reduction above plus scale / shift / mean / rstd of the block's own
+// (group, channel) entries (no ordering needed between groups).  The running statistics -- the only sequential part -- are left to
+// bn_running_kernel, which nothing in the forward or backward pass waits for (the host runs it on the second stream).
+__global__ __launch_bounds__(1024) void bn_stats_kernel(float* __restrict__ stats, int tpg, int Cp, int C, double inv_cnt,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                                        float* __restrict__ rstd_o) {
+    __shared__ double r1[16][64], r2[16][64];
+    const int g = blockIdx.x;
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < Cp) {
+        for (int t = lane; t < tpg; t += 16) {
+            const float2 v = *(const float2*)(stats + (((long)g * tpg + t) * Cp + c) * 2);
+            s1 += v.x;
+            s2 += v.y;
+        }
+    }
+    r1[lane][cl] = s1;
+    r2[lane][cl] = s2;
+    __syncthreads();
+    if (lane == 0 && c < Cp) {
+        s1 = 0.0;
+        s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s1 += r1[k][cl];
+            s2 += r2[k][cl];
+        }
+        const double m = s1 * inv_cnt;
+        double var = s2 * inv_cnt - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        const float mv = (float)m, vv = (float)var;                // exactly what bn_finalize_kernel reads back
+        *(float2*)(stats + ((long)g * tpg * Cp + c) * 2) = make_float2(mv, vv);
+        const bool real = c < C;
+        const float rs = real ? (float)(1.0 / sqrt((double)vv + (double)eps)) : 0.f;
+        const float sc = real ? gamma[c] * rs : 0.f;
+        const long o = (long)g * Cp + c;
+        scale[o] = sc;
+        shift[o] = real ? beta[c] - mv * sc : 0.f;
+        if (mean_o) mean_o[o] = real ? mv : 0.f;
+        if (rstd_o) rstd_o[o] = rs;
+    }
+}
+
+// running_mean / running_var: one momentum step per group IN ORDER (train/unet.py:179,:196 call BatchNorm once per timestep),
+// from the (mean, biased variance) pairs bn_stats_kernel left in the tile-0 slots.
+__global__ void bn_running_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C, double unbias,
+                                  float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = rmean[c], rv = rvar[c];
+    for (int g = 0; g < groups; ++g) {
+        const float2 mv = *(const float2*)(stats + ((long)g * tpg * Cp + c) * 2);
+        const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)g);
+        rm = (1.f - mom) * rm + mom * mv.x;
+        rv = (1.f - mom) * rv + mom * (float)((double)mv.y * unbias);
+    }
+    rmean[c] = rm;
+    rvar[c] = rv;
+}
+
 // Pass 2: per channel, groups IN ORDER (running statistics are a sequential momentum recursion).
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, int tpg, int Cp, int C,
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -978,6 +1041,26 @@ extern "C" int32_t uclstm_bn_finalize(float* stats, int32_t groups, int32_t tile
     }
     UCLSTM_LAUNCH(bn_finalize_kernel, dim3((Cp + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C,
                   unb, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_stats_fwd(float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C, int64_t count_per_group,
+                                       const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                                       void* stream) {
+    if (!stats || groups <= 0 || tiles_per_group <= 0 || Cp <= 0 || C <= 0 || C > Cp || count_per_group <= 0 || !gamma || !beta || !scale || !shift)
+        return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(bn_stats_kernel, dim3(groups, (Cp + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, tiles_per_group, Cp, C,
+                  1.0 / (double)count_per_group, gamma, beta, eps, scale, shift, mean, rstd);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_running_stats(const float* stats, int32_t groups, int32_t tiles_per_group, int32_t Cp, int32_t C,
+                                           int64_t count_per_group, float* running_mean, float* running_var, float momentum, void* stream) {
+    if (!stats || groups <= 0 || tiles_per_group <= 0 || Cp <= 0 || C <= 0 || C > Cp || count_per_group <= 0 || !running_mean || !running_var)
+        return UCLSTM_E_BADARG;
+    const double unb = count_per_group > 1 ? (double)count_per_group / (double)(count_per_group - 1) : 1.0;
+    UCLSTM_LAUNCH(bn_running_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, groups, tiles_per_group, Cp, C, unb,
+                  running_mean, running_var, momentum);
     return UCLSTM_OK;
 }
 #endif

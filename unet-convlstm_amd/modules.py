@@ -170,6 +170,7 @@ class DoubleConv(nn.Module):
 
     def forward(self, x):
         a = self.first_layer_nhwc(x, False, 1)
+        ops.join_forward_side(a.device)
         return ops.FromNHWC.apply(a, self.net[3].out_channels)
 
 
@@ -193,6 +194,7 @@ class Down(nn.Module):
 
     def forward(self, x):
         a = self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()))
+        ops.join_forward_side(a.device)
         return ops.FromNHWC.apply(a, self.net[1].net[3].out_channels)
 
 
@@ -215,6 +217,7 @@ class Up(nn.Module):
 
     def forward(self, x1, x2):
         a = self.forward_nhwc(ops.ToNHWC.apply(x1.contiguous().float()), ops.ToNHWC.apply(x2.contiguous().float()), x2.shape[1])
+        ops.join_forward_side(a.device)
         return ops.FromNHWC.apply(a, self.conv.net[3].out_channels)
 
 
@@ -309,6 +312,7 @@ class TemporalUNetDualView(nn.Module):
     def encode_once(self, x_t):
         """Reference train/unet.py:161-172 on f32 NCHW (public helper, one timestep)."""
         xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
+        ops.join_forward_side(xb.device)
         c = self.base_ch
         f = ops.FromNHWC.apply
         return f(xb, c * 16), (f(x3, c * 8), f(x2, c * 4), f(x1, c * 2), f(x0, c))
@@ -323,6 +327,8 @@ class TemporalUNetDualView(nn.Module):
             _DEFERRED_COUNTERS = None
             if pending:
                 _flush_counters(pending)
+            if x_seq.is_cuda:
+                ops.join_forward_side(x_seq.device)      # BatchNorm running statistics were updated on the second stream
 
     def _forward(self, x_seq, state=None):
         B, T, Cc, H, W = x_seq.shape
@@ -385,6 +391,7 @@ class TemporalUNetDualView(nn.Module):
         d2 = self.up2.forward_nhwc(d3, x2, c * 4, 1)
         d1 = self.up1.forward_nhwc(d2, x1, c * 2, 1)
         d0 = self.up0.forward_nhwc(d1, x0, c, 1)
+        ops.join_forward_side(d0.device)
         return self.outc.forward_nhwc(d0), new_state
 
 

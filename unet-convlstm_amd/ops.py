@@ -426,6 +426,8 @@ def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0, dtype=
 
 def pack_bias(desc: L.PackDesc, b: torch.Tensor) -> torch.Tensor:
     _dev(b, F32, "bias")
+    if desc.n_mode == L.NMODE_IDENTITY and desc.N == desc.n_valid == b.numel() and b.is_contiguous() and b.data_ptr() % 16 == 0:
+        return b.detach()          # panel-row order == channel order and no padding rows: the bias IS its panel (no kernel)
     bp = torch.empty((desc.N,), dtype=F32, device=b.device)
     L.check(L.lib.uclstm_pack_bias(C.byref(desc), _p(b), _p(bp), _stream()), "pack_bias")
     return bp
@@ -454,6 +456,20 @@ def _slabs_of(dwp: torch.Tensor) -> Tuple[int, int]:
 # (autograd engine callback), before anything can read the gradients.  ``GRAD_SIDE_HOOKS`` lets data-parallel code learn
 # that a parameter's gradient has been enqueued (the hook runs with the side stream current).
 ASYNC_WGRAD = os.environ.get("UCLSTM_ASYNC_WGRAD", "1") != "0"
+BN_RUNNING_ON_SIDE = os.environ.get("UCLSTM_BN_RUNNING_ON_SIDE", "1") != "0"     # running-statistics recursion on the second stream
+_FWD_SIDE_PENDING: set = set()
+
+
+def join_forward_side(device) -> None:
+    """Make the current stream wait for forward-pass work that was put on the second stream (BatchNorm running statistics).
+    Called where such results become observable: at the end of a module's public forward, before evaluation-mode
+    BatchNorm reads the running statistics; the backward pass joins the second stream anyway."""
+    key = str(device)
+    if key in _FWD_SIDE_PENDING:
+        _FWD_SIDE_PENDING.discard(key)
+        torch.cuda.current_stream(device).wait_stream(side_stream(device))
+
+
 PARAM_GRADS_ON_SIDE = os.environ.get("UCLSTM_PARAM_GRADS_ON_SIDE", "1") != "0"   # BatchNorm parameter gradients on the weight-gradient stream
 HOIST_X = os.environ.get("UCLSTM_HOIST_X", "0") == "1"               # x half of the ConvLSTM gate conv as one GEMM over all T (off: measured slower, DESIGN.md section 6)
 POOL_SKIP = os.environ.get("UCLSTM_POOL_SKIP", "1") != "0"            # skip-connection gradient added inside max-pool backward
@@ -954,9 +970,22 @@ class ConvBNReLU(torch.autograd.Function):
             z = out
             igemm_store(srcs, wp, (H, W), n_img, [(z, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=groups, bias=bp, stats=stats)
             par = torch.empty((4, groups, Cop), dtype=F32, device=dev)     # scale, shift, mean, rstd
-            L.check(L.lib.uclstm_bn_finalize(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), _p(running_mean),
-                                             _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
-                                             _stream()), "bn_finalize")
+            if ASYNC_WGRAD and BN_RUNNING_ON_SIDE and not torch.cuda.is_current_stream_capturing():
+                # critical part in one launch (reduction + scale / shift / mean / rstd); the in-order running-statistics recursion,
+                # which nothing in this step waits for, on the second stream (joined at the end of the forward pass: join_forward_side)
+                L.check(L.lib.uclstm_bn_stats_fwd(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), eps, _p(par[0]), _p(par[1]),
+                                                  _p(par[2]), _p(par[3]), _stream()), "bn_stats_fwd")
+                main, side = torch.cuda.current_stream(dev), side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    L.check(L.lib.uclstm_bn_running_stats(_p(stats), groups, tpg, Cop, Co, ppg, _p(running_mean), _p(running_var), momentum,
+                                                          _stream()), "bn_running_stats")
+                    stats.record_stream(side)
+                _FWD_SIDE_PENDING.add(str(dev))
+            else:
+                L.check(L.lib.uclstm_bn_finalize(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), _p(running_mean),
+                                                 _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
+                                                 _stream()), "bn_finalize")
             a = torch.empty_like(z)
             _timed_hbm("bn_apply_relu", 4.0 * z.numel(),        # 2 B read + 2 B written per element
                        lambda: L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
@@ -965,6 +994,7 @@ class ConvBNReLU(torch.autograd.Function):
             if need_bw:
                 note_use(weight, gamma, beta, bias)
         elif need_bw:
+            join_forward_side(dev)
             # evaluation-mode statistics WITH a backward pass (fine-tuning through frozen BatchNorm): keep the pre-BN conv
             # output like the training path does, normalise with the running statistics as one group
             groups = 1
@@ -979,6 +1009,7 @@ class ConvBNReLU(torch.autograd.Function):
             ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
             note_use(weight, gamma, beta, bias)
         else:
+            join_forward_side(dev)
             par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
             L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                              momentum, eps, _p(par[0]), _p(par[1]), None, None, _stream()), "bn_finalize(eval)")
