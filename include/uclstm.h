@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 9
+#define UCLSTM_ABI_VERSION 10
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -183,6 +183,22 @@ typedef struct {
 /* f32 reference layout (OIHW conv weight, train/unet.py:19,:70; [in,out,2,2] convT weight, :90)
  * -> bf16 panel [N][Ktot] (zero padded). */
 int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w, void* wp, void* stream);
+/* Batched packing: a training step repacks every panel after the optimiser step (~100 launches of 3-15 us: a latency chain the
+ * step's first convolutions wait for).  Descriptors, pointers and block ranges are the same every step, so the host fills a
+ * job table once (uclstm_pack_job_init, host side: returns the job's kernel family 0..4 and fills gx / nblocks / div; block0 =
+ * running sum of nblocks over the jobs of ONE family), copies it to the device, and launches one kernel per family. */
+typedef struct {
+    uclstm_pack_desc d;
+    const float* w;
+    void* wp;
+    int32_t block0, nblocks, gx, family;
+    uint32_t div[15];
+    int32_t pad_;
+} uclstm_pack_job;
+int32_t uclstm_pack_job_init(uclstm_pack_job* job /* HOST memory */, const uclstm_pack_desc* d, const float* w, void* wp, int32_t block0);
+int32_t uclstm_pack_weights_batched(const uclstm_pack_job* jobs_dev /* DEVICE memory, jobs of one family ordered by block0 */,
+                                    int32_t njobs, int32_t family, int32_t total_blocks, void* stream);
+
 /* f32 panel gradient [N][Ktot] -> f32 gradient in the reference layout:
  * grad = (accumulate ? grad : 0) + dWp  on every valid element.  With more than 64 slabs the slabs are first folded into
  * slab 0 in place: dwp is scratch of the weight-gradient GEMM and is CONSUMED by this call. */
@@ -372,6 +388,7 @@ int32_t uclstm_stream_spin(int32_t microseconds, void* stream);
 UCLSTM_F16_TWIN(uclstm_igemm_fwd)
 UCLSTM_F16_TWIN(uclstm_igemm_wgrad)
 UCLSTM_F16_TWIN(uclstm_pack_weights)
+UCLSTM_F16_TWIN(uclstm_pack_weights_batched)
 UCLSTM_F16_TWIN(uclstm_bn_apply_relu)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_reduce)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_apply)

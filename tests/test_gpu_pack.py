@@ -112,3 +112,55 @@ def test_unpack_adds_the_slabs_into_the_reference_layout(name, nslab):
         L.check(L.lib.uclstm_unpack_wgrad(d, sd.data_ptr(), ns, st, grad.data_ptr(), acc, None), "unpack")
         ref = torch.from_numpy(want).view(wshape) + (base.double() if acc else 0)
         torch.testing.assert_close(grad.cpu().double(), ref, rtol=1e-5, atol=1e-4 if nslab > 64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_batched_packing_equals_the_single_panel_kernels(dtype):
+    """uclstm_pack_weights_batched (one launch per kernel family over a device job table, the look-ahead packing of a training
+    step) must write bit for bit what uclstm_pack_weights writes panel by panel -- every family, both 16-bit types."""
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(3)
+    items = []
+    for name, mk in CASES.items():
+        d, wshape, off = mk()
+        w = torch.randn(wshape, generator=g).to(DEV)
+        items.append(((w.data_ptr(), off, bytes(d), dt), d, w, off))
+    batch = ops._PackBatch(items)
+    fams = sorted({f for launches in batch.segments for _, f, _, _, _ in launches})
+    assert len(batch.segments) > 1 and fams == [0, 1, 2, 3], fams       # every family the model's panels fall into (4: unused)
+    for wp, _ in batch.panels.values():
+        wp.fill_(7.0)
+    batch.launch(torch.cuda.current_stream())
+    assert all(e is not None for e in batch.events)
+    torch.cuda.synchronize()
+    for (key, d, w, off), name in zip(items, CASES):
+        want = ops.pack_weights(d, w, off, dtype=dt)
+        got = batch.panels[key][0]
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), name
+
+
+def test_look_ahead_packing_hands_out_the_batched_panels():
+    """prepack_begin() replays the previous step's pack calls as batched launches; pack_weights() then returns those panels."""
+    g = torch.Generator().manual_seed(4)
+    calls = []
+    for name in ("conv fwd 2 sources", "conv dgrad", "lstm fwd", "convT fwd", "first layer"):
+        d, wshape, off = CASES[name]()
+        calls.append((d, torch.randn(wshape, generator=g).to(DEV), off))
+    try:
+        ops.prepack_begin()                                   # step 0: records
+        first = [ops.pack_weights(d, w, off).clone() for d, w, off in calls]
+        ops.prepack_end()
+        for _, w, _ in calls:
+            w.mul_(0.5)                                       # "optimiser step"
+        ops.prepack_begin()                                   # step 1: packs ahead
+        assert ops._PACK_BATCH is not None and len(ops._PACK_READY) == len(calls)
+        second = [ops.pack_weights(d, w, off) for d, w, off in calls]
+        assert all(p.data_ptr() == ops._PACK_BATCH.panels[k][0].data_ptr() for p, k in zip(second, ops._PACK_BATCH.sig))
+        ops.prepack_end()
+        torch.cuda.synchronize()
+        for a, b, (d, w, off) in zip(first, second, calls):
+            assert torch.equal(b.view(torch.int16), ops.pack_weights(d, w, off).view(torch.int16))
+            assert not torch.equal(a, b)
+    finally:
+        ops.prepack_end()
+        ops._PACK_PLAN.clear()

@@ -44,3 +44,7 @@ for q, lst in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1]
         a[1] += 1
     for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
         print(f"    {t / 1e6:7.3f} ms  x{c:4d}  {n}")
+    big = sorted(((lst[i + 1][0] - lst[i][1], i) for i in range(len(lst) - 1)), reverse=True)[:6]
+    for g, i in big:
+        if g > 20000:
+            print(f"    gap {g / 1e3:7.1f} us  at +{(lst[i][1] - lo) / 1e6:6.3f} ms  after {short(lst[i][2])[:40]}  before {short(lst[i + 1][2])[:40]}")

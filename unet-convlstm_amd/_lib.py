@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -76,6 +76,12 @@ class PackDesc(C.Structure):
                 ("stride_ntap", C.c_int64)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("d", PackDesc), ("w", C.c_void_p), ("wp", C.c_void_p),
+                ("block0", C.c_int32), ("nblocks", C.c_int32), ("gx", C.c_int32), ("family", C.c_int32),
+                ("div", C.c_uint32 * 15), ("pad_", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (restype int32 unless listed in _RESTYPES)
@@ -88,6 +94,8 @@ _PROTOS = {
     "uclstm_igemm_wgrad_splits": [C.POINTER(WgradDesc)],
     "uclstm_igemm_wgrad_shape": [C.POINTER(WgradDesc)],
     "uclstm_pack_weights": [C.POINTER(PackDesc), _P, _P, _P],
+    "uclstm_pack_job_init": [C.POINTER(PackJob), C.POINTER(PackDesc), _P, _P, _I],
+    "uclstm_pack_weights_batched": [_P, _I, _I, _I, _P],
     "uclstm_unpack_wgrad": [C.POINTER(PackDesc), _P, _I, _L, _P, _I, _P],
     "uclstm_pack_bias": [C.POINTER(PackDesc), _P, _P, _P],
     "uclstm_bn_finalize": [_P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
@@ -130,7 +138,7 @@ _RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_ch
 
 
 # entry points that exist twice: name (bfloat16) and name_f16 (IEEE binary16), identical signatures (include/uclstm.h)
-F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
+F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_pack_weights_batched', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
 
 
 def header_symbols() -> list[str]:

@@ -12,6 +12,7 @@
 #define uclstm_igemm_fwd uclstm_igemm_fwd_f16
 #define uclstm_igemm_wgrad uclstm_igemm_wgrad_f16
 #define uclstm_pack_weights uclstm_pack_weights_f16
+#define uclstm_pack_weights_batched uclstm_pack_weights_batched_f16
 #define uclstm_bn_apply_relu uclstm_bn_apply_relu_f16
 #define uclstm_bn_bwd_reduce uclstm_bn_bwd_reduce_f16
 #define uclstm_bn_bwd_apply uclstm_bn_bwd_apply_f16

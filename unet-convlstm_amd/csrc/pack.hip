@@ -79,14 +79,18 @@ __device__ __forceinline__ Decoded decode(const uclstm_pack_desc& d, const PackD
     return r;
 }
 
-__global__ void pack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w, act16* __restrict__ wp) {
+__device__ __forceinline__ void pack_generic_body(const uclstm_pack_desc& d, const PackDiv& dv, const float* __restrict__ w,
+                                                  act16* __restrict__ wp, uint32_t block, uint32_t nblocks) {
     const uint32_t total = (uint32_t)d.N * (uint32_t)d.Ktot;       // < 2^31 (checked by the launcher)
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (uint32_t idx = block * blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
         const int n = (int)fdiv(idx, dv.ktot);
         const int k = (int)(idx - (uint32_t)n * (uint32_t)d.Ktot);
         const Decoded r = decode(d, dv, n, k);
         wp[idx] = f32_to_act(r.valid ? w[r.off] : 0.f);
     }
+}
+__global__ void pack_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w, act16* __restrict__ wp) {
+    pack_generic_body(d, dv, w, wp, blockIdx.x, gridDim.x);
 }
 
 // grid.y > 1 (accumulate only): slab group blockIdx.y adds its share of the slabs with one f32 atomic per element -- for the
@@ -119,13 +123,13 @@ __global__ void unpack_kernel(const uclstm_pack_desc d, const PackDiv dv, const 
 // unpack, ConvTranspose input-gradient panels): for one panel row the (channel, tap) block of a source is ONE contiguous
 // run of channels*taps floats.  Block = (panel row, source, 256-channel chunk).
 template <int TAPS, bool UNPACK>
-__global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
-                                                        act16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
-                                                        float* __restrict__ grad, int accumulate, int chunks0) {
+__device__ __forceinline__ void pack_rows_body(const uclstm_pack_desc& d, const PackDiv& dv, const float* __restrict__ w,
+                                               act16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
+                                               float* __restrict__ grad, int accumulate, int chunks0, int bx, int by) {
     __shared__ float buf[256 * TAPS];
-    const int n = blockIdx.y;
-    const int s = (int)blockIdx.x >= chunks0 ? 1 : 0;
-    const int c0 = ((int)blockIdx.x - (s ? chunks0 : 0)) * 256;
+    const int n = by;
+    const int s = bx >= chunks0 ? 1 : 0;
+    const int c0 = (bx - (s ? chunks0 : 0)) * 256;
     const int seg = s ? d.kseg[1] : d.kseg[0];
     const int per_tap = d.kseg[0] + d.kseg[1];
     int n_ent, tapn;
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d
 #pragma unroll
             for (int i = 0; i < TAPS; ++i) {
                 const int e = i * 256 + threadIdx.x;
-                v[i] = e < count ? w[roff + e] : 0.f;
+                const float x = w[e < count ? roff + e : 0];         // branch-free: see pack_transposed_body
+                v[i] = e < count ? x : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < TAPS; ++i) {
@@ -188,20 +193,30 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d
     }
 }
 
+template <int TAPS, bool UNPACK>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
+                                                        act16* __restrict__ wp, const float* __restrict__ dwp, int nslab, int64_t slab,
+                                                        float* __restrict__ grad, int accumulate, int chunks0) {
+    pack_rows_body<TAPS, UNPACK>(d, dv, w, wp, dwp, nslab, slab, grad, accumulate, chunks0, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // "Transposed" family (n_mode IDENTITY, stride_n == taps, stride_tap == 1: conv / ConvLSTM input-gradient panels; the panel
 // row is the INPUT channel, the K column an output channel or gate channel): for one K column the (row, tap) block of 16
 // consecutive panel rows is one contiguous run of 16*taps floats.  Block = 16 panel rows x 64 K columns.
+// (64-row tiles -- 2.3-KiB runs, 512 threads, 72 KiB of LDS -- were tried and are no faster: 2.3-2.9 TB/s against 2.4-3.1 TB/s,
+// tools/bench_boundary.py; what held the first version at 1.4 TB/s of reads was not the run length but loads under a condition.)
 template <int TAPS>
-__global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
-                                                              act16* __restrict__ wp) {
-    constexpr int RUN = 16 * TAPS;
-    constexpr int PITCH = RUN + 2;                                    // in act16: 73 dwords per column, odd -> conflict-free column walks
-    constexpr int NLD = 4 * TAPS;                                     // 64 * RUN / 256 loads per thread
+__device__ __forceinline__ void pack_transposed_body(const uclstm_pack_desc& d, const PackDiv& dv, const float* __restrict__ w,
+                                                     act16* __restrict__ wp, int bx, int by) {
+    constexpr int ROWS = 16, NTHR = 256;
+    constexpr int RUN = ROWS * TAPS;
+    constexpr int PITCH = RUN + 2;                                    // in act16: an odd number of dwords per column -> conflict-free column walks
+    constexpr int NLD = 64 * RUN / NTHR;                              // loads per thread
     __shared__ act16 buf[64 * PITCH];                                  // 18 KiB (already rounded: the panel is act16), small enough
                                                                       // to share a CU with a 128-KiB weight-gradient block
     __shared__ int64_t kbase[64];
-    const int kc0 = blockIdx.x * 64;
-    const int n0 = blockIdx.y * 16;
+    const int kc0 = bx * 64;
+    const int n0 = by * ROWS;
     const int per_tap = d.kseg[0] + d.kseg[1];
     if (threadIdx.x < 64) {
         const int c = kc0 + threadIdx.x;                              // single source (nsrc == 1 in this family)
@@ -217,22 +232,26 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
     }
     __syncthreads();
     int nrow = d.n_valid - n0;
-    nrow = nrow < 0 ? 0 : (nrow > 16 ? 16 : nrow);
+    nrow = nrow < 0 ? 0 : (nrow > ROWS ? ROWS : nrow);
     const int run = nrow * TAPS;
     // ALL of the block's loads are issued before the first LDS store (the first version kept four in flight per thread and was
     // latency-bound at 0.6 TB/s: 4096 blocks x 9 dependent load batches).  Consecutive lanes read consecutive floats of a
-    // column's contiguous (16 rows x taps) run.
+    // column's contiguous (ROWS rows x taps) run.
     float v[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-        const int e = u * 256 + threadIdx.x;
+        const int e = u * NTHR + threadIdx.x;
         const int kl = e / RUN, r = e - kl * RUN;
         const int64_t kb = kbase[kl];
-        v[u] = (r < run && kb >= 0) ? w[kb + (int64_t)n0 * TAPS + r] : 0.f;
+        // unconditional load from a clamped address + select: a load under a condition compiles to a branch with its own
+        // s_waitcnt vmcnt(0), i.e. one round trip per element instead of all loads in flight (reads at 1.4 TB/s)
+        const bool ok = r < run && kb >= 0;
+        const float x = w[ok ? kb + (int64_t)n0 * TAPS + r : 0];
+        v[u] = ok ? x : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-        const int e = u * 256 + threadIdx.x;
+        const int e = u * NTHR + threadIdx.x;
         const int kl = e / RUN, r = e - kl * RUN;
         buf[kl * PITCH + r] = f32_to_act(v[u]);
     }
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
     // and stores 16 bytes (the first version stored 2 bytes per lane: 36 store instructions per thread instead of 4.5)
     const int g8 = threadIdx.x & 7;
     const bool full = kc0 + 64 <= per_tap;
-    for (int sgm = threadIdx.x >> 3; sgm < RUN; sgm += 32) {
+    for (int sgm = threadIdx.x >> 3; sgm < RUN; sgm += NTHR / 8) {
         const int nl = sgm / TAPS, t = sgm - nl * TAPS;
         if (n0 + nl >= d.N) continue;
         const int ts = d.tap_flip ? TAPS - 1 - t : t;
@@ -257,6 +276,64 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_
                 if (kc0 + g8 * 8 + j < per_tap) dst[j] = o.e[j];
         }
     }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void pack_transposed_kernel(const uclstm_pack_desc d, const PackDiv dv, const float* __restrict__ w,
+                                                              act16* __restrict__ wp) {
+    pack_transposed_body<TAPS>(d, dv, w, wp, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- batched packing: ALL panels of one kernel family in one launch ------------------------------------------------------
+// A training step repacks ~100 panels; as separate 3-15 us launches on one stream they are a latency chain of ~0.7-1 ms that the
+// first convolutions of the step wait for (profiles/round2_notes.md).  The host fills a job table once (descriptors, pointers and
+// block ranges are the same every step) and launches one kernel per family; a block finds its job by binary search over the
+// block offsets and runs the same body as the single-panel kernel.
+struct JobView {
+    uclstm_pack_desc d;
+    PackDiv dv;
+    const float* w;
+    act16* wp;
+    int lb, gx, nblocks;
+};
+__device__ __forceinline__ JobView find_job(const uclstm_pack_job* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const uclstm_pack_job& J = jobs[lo];
+    JobView v;
+    v.d = J.d;
+    const uint32_t* q = J.div;
+    v.dv.ktot = FastDiv{q[0], q[1], q[2]};
+    v.dv.per_tap = FastDiv{q[3], q[4], q[5]};
+    v.dv.n_cp = FastDiv{q[6], q[7], q[8]};
+    v.dv.k_hdp = FastDiv{q[9], q[10], q[11]};
+    v.dv.k_hd = FastDiv{q[12], q[13], q[14]};
+    v.w = J.w;
+    v.wp = (act16*)J.wp;
+    v.lb = (int)blockIdx.x - J.block0;
+    v.gx = J.gx;
+    v.nblocks = J.nblocks;
+    return v;
+}
+template <int TAPS>
+__global__ __launch_bounds__(256) void pack_rows_batched_kernel(const uclstm_pack_job* __restrict__ jobs, int njobs) {
+    const JobView v = find_job(jobs, njobs);
+    const int by = v.lb / v.gx, bx = v.lb - by * v.gx;
+    pack_rows_body<TAPS, false>(v.d, v.dv, v.w, v.wp, nullptr, 0, 0, nullptr, 0, (v.d.kseg[0] + 255) / 256, bx, by);
+}
+template <int TAPS>
+__global__ __launch_bounds__(256) void pack_transposed_batched_kernel(const uclstm_pack_job* __restrict__ jobs, int njobs) {
+    const JobView v = find_job(jobs, njobs);
+    const int by = v.lb / v.gx, bx = v.lb - by * v.gx;
+    pack_transposed_body<TAPS>(v.d, v.dv, v.w, v.wp, bx, by);
+}
+__global__ void pack_generic_batched_kernel(const uclstm_pack_job* __restrict__ jobs, int njobs) {
+    const JobView v = find_job(jobs, njobs);
+    pack_generic_body(v.d, v.dv, v.w, v.wp, (uint32_t)v.lb, (uint32_t)v.nblocks);
 }
 
 // Many-slab panels (C_out <= 64 layers: 64 x 576 elements x ~170 pixel-range slabs): slab 0 += slabs 1..nslab-1 in slab order
@@ -343,6 +420,57 @@ extern "C" int32_t uclstm_pack_weights(const uclstm_pack_desc* d, const float* w
         return UCLSTM_OK;
     }
     UCLSTM_LAUNCH(pack_kernel, dim3(grid_for((int64_t)d->N * d->Ktot)), dim3(256), 0, (hipStream_t)stream, *d, make_pack_div(*d), w, (act16*)wp);
+    return UCLSTM_OK;
+}
+
+
+#ifndef UCLSTM_ACT_F16
+// family of a descriptor: 0 generic, 1 rows (9 taps), 2 rows (4 taps), 3 transposed (9 taps), 4 transposed (4 taps)
+static int pack_family(const uclstm_pack_desc& d) {
+    if (rows_family(d)) return d.taps == 9 ? 1 : 2;
+    if (transposed_family(d)) return d.taps == 9 ? 3 : 4;
+    return 0;
+}
+
+extern "C" int32_t uclstm_pack_job_init(uclstm_pack_job* job, const uclstm_pack_desc* d, const float* w, void* wp, int32_t block0) {
+    if (!job || !desc_ok(d) || !w || !wp || block0 < 0) return UCLSTM_E_BADARG;
+    job->d = *d;
+    job->w = w;
+    job->wp = wp;
+    job->block0 = block0;
+    job->family = pack_family(*d);
+    if (job->family == 1 || job->family == 2) {
+        job->gx = (d->kseg[0] + 255) / 256 + (d->kseg[1] + 255) / 256;
+        job->nblocks = job->gx * d->N;
+    } else if (job->family >= 3) {
+        job->gx = (d->kseg[0] + d->kseg[1] + 63) / 64;
+        job->nblocks = job->gx * ((d->N + 15) / 16);
+    } else {
+        job->gx = grid_for((int64_t)d->N * d->Ktot);
+        job->nblocks = job->gx;
+    }
+    const PackDiv v = make_pack_div(*d);
+    const FastDiv fs[5] = {v.ktot, v.per_tap, v.n_cp, v.k_hdp, v.k_hd};
+    for (int i = 0; i < 5; ++i) {
+        job->div[3 * i] = fs[i].magic;
+        job->div[3 * i + 1] = fs[i].shift;
+        job->div[3 * i + 2] = fs[i].d;
+    }
+    job->pad_ = 0;
+    return job->family;
+}
+#endif
+
+extern "C" int32_t uclstm_pack_weights_batched(const uclstm_pack_job* jobs_dev, int32_t njobs, int32_t family, int32_t total_blocks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || family < 0 || family > 4) return UCLSTM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (family) {
+        case 1: UCLSTM_LAUNCH(pack_rows_batched_kernel<9>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs); break;
+        case 2: UCLSTM_LAUNCH(pack_rows_batched_kernel<4>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs); break;
+        case 3: UCLSTM_LAUNCH(pack_transposed_batched_kernel<9>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs); break;
+        case 4: UCLSTM_LAUNCH(pack_transposed_batched_kernel<4>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs); break;
+        default: UCLSTM_LAUNCH(pack_generic_batched_kernel, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs); break;
+    }
     return UCLSTM_OK;
 }
 

@@ -610,8 +610,11 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, uint4* __restri
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            // load from a clamped address, then select: a load under a condition becomes a branch with its own s_waitcnt
+            // vmcnt(0) -- eight round trips per thread instead of eight loads in flight
             const int c = cc * 8 + i;
-            v[i] = c < C ? src[(int64_t)c * HW + pix] : 0.f;
+            const float t8 = src[(int64_t)(c < C ? c : 0) * HW + pix];
+            v[i] = c < C ? t8 : 0.f;
         }
         out[((int64_t)img * HW + pix) * cpc + cc] = pack8(v);
     }
@@ -682,7 +685,9 @@ __global__ void im2col_first_kernel(const float* __restrict__ x, uint4* __restri
             const uint32_t tap = fdiv(k, dC);
             const int c = (int)(k - tap * C);
             const int ys = y + (int)(tap / 3) - 1, xs = xx + (int)(tap % 3) - 1;
-            v[i] = (tap < 9 && (unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W) ? src[(int64_t)c * HW + ys * W + xs] : 0.f;
+            const bool ok = tap < 9 && (unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W;
+            const float t8 = src[ok ? (int64_t)c * HW + ys * W + xs : 0];          // branch-free, as in nchw_to_nhwc_kernel
+            v[i] = ok ? t8 : 0.f;
         }
         out[((int64_t)img * HW + pix) * kpc + kc] = pack8(v);
     }
@@ -758,9 +763,13 @@ __global__ void outconv_bwd_da_kernel(const float* __restrict__ w, const float* 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = cc * 8 + i;
-                if (c < C) o[i] += g * w[co * C + c];
+                const float wv = w[co * C + (c < C ? c : 0)];                      // branch-free, as in nchw_to_nhwc_kernel
+                o[i] += g * (c < C ? wv : 0.f);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((int)(cc * 8 + i) >= C) o[i] = 0.f;                               // padding channels stay exactly zero (g may be inf)
         da[idx] = pack8(o);
     }
 }

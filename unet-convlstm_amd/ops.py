@@ -361,9 +361,81 @@ _PACK_READY: dict = {}         # key -> (panel, event) produced by prepack_begin
 _PACK_RECORDING = False
 
 
+PACK_BATCHED = os.environ.get("UCLSTM_PACK_BATCHED", "1") != "0"
+
+
+PACK_SEGMENTS = tuple(float(x) for x in os.environ.get("UCLSTM_PACK_SEGMENTS", "0.02,0.08,0.2,0.35,0.5,0.65,0.8").split(",") if x)
+
+
+class _PackBatch:
+    """All look-ahead panels of a step as a few launches per kernel family (uclstm_pack_weights_batched).
+
+    The job table (descriptors, weight and panel pointers, block ranges) is built once and lives on the device; the panels
+    are persistent, which is safe inside train_step: the step's packing waits for everything the main stream has been
+    given (side.wait_stream(main) in prepack_begin), i.e. for the last reader of the previous step.
+
+    The panels are cut, in order of first use, into segments at the cumulative byte fractions PACK_SEGMENTS; a segment is one
+    launch per family followed by an event, so the step's first convolutions wait for the first few per cent of the bytes
+    only.  (Holding the later segments back until the main stream reaches the MFMA-bound layers was tried and measured no
+    different: packing is ~0.55 ms of HBM traffic per step and costs about that wherever it runs, profiles/round2_notes.md.)
+    """
+
+    def __init__(self, items):
+        self.sig = tuple(key for key, _, _, _ in items)
+        self.panels, self.keep, self.segments = {}, [], []            # segments: [[(dtype, fam, byte offset, njobs, blocks)]]
+        dev = items[0][2].device
+        sizes = [desc.N * desc.Ktot for _, desc, _, _ in items]
+        total, run, seg_of = float(sum(sizes)), 0, []
+        for sz in sizes:
+            seg_of.append(sum(1 for f in PACK_SEGMENTS if run >= f * total))
+            run += sz
+        jobs_all = []
+        for n, seg in enumerate(sorted(set(seg_of))):
+            groups: dict = {}
+            for (key, desc, w, off), sg in zip(items, seg_of):
+                if sg != seg:
+                    continue
+                wp = torch.empty((desc.N, desc.Ktot), dtype=key[3], device=dev)
+                job = L.PackJob()
+                fam = L.lib.uclstm_pack_job_init(C.byref(job), C.byref(desc), C.c_void_p(w.data_ptr() + 4 * off), _p(wp), 0)
+                L.check(min(fam, 0), "pack_job_init")
+                groups.setdefault((key[3], fam), []).append(job)
+                self.panels[key] = (wp, n)
+                self.keep.append(w)
+            launches = []
+            for (dtype, fam), jobs in groups.items():
+                b0, first = 0, len(jobs_all)
+                for j in jobs:
+                    j.block0 = b0
+                    b0 += j.nblocks
+                    jobs_all.append(j)
+                launches.append((dtype, fam, first * C.sizeof(L.PackJob), len(jobs), b0))
+            self.segments.append(launches)
+        arr = (L.PackJob * len(jobs_all))(*jobs_all)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.events: list = [None] * len(self.segments)
+
+    def launch(self, side) -> None:
+        """Launch every segment on ``side``; events[s] is recorded behind segment s."""
+        base, st = self.table.data_ptr(), C.c_void_p(side.cuda_stream)
+        for sg, launches in enumerate(self.segments):
+            for dtype, fam, byte_off, n, blocks in launches:
+                L.check(L.kernels(dtype).uclstm_pack_weights_batched(C.c_void_p(base + byte_off), n, fam, blocks, st), "pack_weights_batched")
+            self.events[sg] = torch.cuda.Event()
+            self.events[sg].record(side)
+
+    def panel(self, key, main) -> torch.Tensor:
+        wp, sg = self.panels[key]
+        main.wait_event(self.events[sg])
+        return wp
+
+
+_PACK_BATCH: Optional[_PackBatch] = None
+
+
 def prepack_begin() -> None:
     """Start of a training step whose parameters will not change before its backward pass has run."""
-    global _PACK_RECORDING, _PACK_PLAN
+    global _PACK_RECORDING, _PACK_PLAN, _PACK_BATCH
     _PACK_READY.clear()
     _PACK_RECORDING = False
     if not PREPACK:
@@ -374,6 +446,21 @@ def prepack_begin() -> None:
         return
     dev = plan[0][2].device
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    if PACK_BATCHED:
+        items, seen = [], set()
+        for it in plan:
+            if it[0] not in seen and it[2].data_ptr() == it[0][0]:
+                seen.add(it[0])
+                items.append(it)
+        if not items:
+            return
+        if _PACK_BATCH is None or _PACK_BATCH.sig != tuple(it[0] for it in items):
+            _PACK_BATCH = _PackBatch(items)          # panels allocated on the main stream: their later reuse is ordered there
+        side.wait_stream(main)                       # the optimiser step that produced these weights + the panels' last readers
+        _PACK_BATCH.launch(side)
+        for key in _PACK_BATCH.panels:
+            _PACK_READY[key] = _PACK_BATCH
+        return
     side.wait_stream(main)                       # the optimiser step that produced these weights
     with torch.cuda.stream(side):
         for key, desc, w, off in plan:
@@ -405,7 +492,10 @@ def pack_weights(desc: L.PackDesc, w: torch.Tensor, elem_offset: int = 0, dtype=
         _PACK_PLAN.append((key, d2, w, elem_offset))
         hit = _PACK_READY.get(key)
         if hit is not None:
-            torch.cuda.current_stream(w.device).wait_event(hit[1])
+            main = torch.cuda.current_stream(w.device)
+            if hit is _PACK_BATCH:
+                return hit.panel(key, main)
+            main.wait_event(hit[1])
             return hit[0]
         key = None
     cache = _ACTIVE_CACHE
