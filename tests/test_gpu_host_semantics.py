@@ -159,3 +159,38 @@ def test_launches_beyond_the_descriptor_range_are_split_bit_identically(monkeypa
     monkeypatch.setattr(ops, "LAUNCH_BYTES_LIMIT", 16 * 16 * 32 * 2 - 1)
     with pytest.raises(U.UclstmError, match="exceeds"):
         run()
+
+
+def test_forward_under_no_grad_takes_the_inference_path_and_counts_no_uses():
+    """ctx.needs_input_grad ignores torch.no_grad() and Function.forward always runs with grad mode off: round 2 took the
+    'backward will follow' branch for every forward whose parameters require grad -- eval-mode BatchNorm ran as finalize +
+    apply kernels in the rollout instead of folded into the conv epilogue, and a validation pass under no_grad bumped the
+    data-parallel use counts.  The caller's grad mode now decides."""
+    torch.manual_seed(29)
+    blk = U.Down(8, 16).to(DEV)
+    x = torch.randn(2, 8, 16, 16, device=DEV)
+    uses = []
+    ops.USE_HOOKS.append(lambda p: uses.append(p))
+    try:
+        for mode in (blk.train, blk.eval):
+            mode()
+            uses.clear()
+            with torch.no_grad():
+                blk(x)
+            assert not uses, f"{len(uses)} parameter uses counted under no_grad"
+            blk(x)
+            assert len(uses) >= 8                                    # two conv stages: weight, bias, gamma, beta each
+    finally:
+        ops.USE_HOOKS.pop()
+    blk.eval()
+    with torch.no_grad():
+        folded = blk(x)                                              # BatchNorm folded into the conv epilogue (one rounding)
+    kept = blk(x).detach()                                           # backward possible: conv output kept, BN as its own pass
+    assert rel_l2(folded, kept) <= 6e-3                              # they differ by one bf16 rounding of the conv output
+    cache = ops.PanelCache()
+    with cache, torch.no_grad():
+        blk(x)
+        n = len(cache.entries)
+        assert any(k[0] == "bn_eval" for k in cache.entries if isinstance(k[0], str))
+        again = blk(x)
+        assert len(cache.entries) == n and torch.equal(again, folded)

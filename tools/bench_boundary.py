@@ -79,3 +79,14 @@ t = timed(lambda: opt.step())
 print(f"optimiser step (sumsq + adamw): {t:.1f} us, {32 * n / t / 1e3:.1f} GB/s")
 t = timed(lambda: g.zero_())
 print(f"zero the gradient buffer: {t:.1f} us, {4 * n / t / 1e3:.1f} GB/s")
+
+# weight-gradient unpack (f32 panel slabs -> f32 gradient in the reference layout) of the three ConvLSTM weights, slab counts as in
+# the benchmark step's range plan
+for name, Hd, nslab in (("temporal", 1024, 1), ("skip3", 512, 5), ("skip2", 256, 7)):
+    d = ops.lstm_wgrad_unpack_desc(Hd, Hd)
+    slabs = torch.randn((nslab, d.N, d.Ktot), device=dev)
+    grad = torch.zeros((4 * Hd, 2 * Hd, 3, 3), device=dev)
+    ns, sl = ops._slabs_of(slabs)
+    t = timed(lambda: L.check(L.lib.uclstm_unpack_wgrad(C.byref(d), slabs.data_ptr(), ns, sl, grad.data_ptr(), 0, C.c_void_p(st.cuda_stream)), "unpack"))
+    nb = 4 * d.N * d.Ktot * nslab + 4 * grad.numel()
+    print(f"unpack {name} ({nslab} slabs): {t:.1f} us, {nb / t / 1e3:.1f} GB/s")

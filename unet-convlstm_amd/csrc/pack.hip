@@ -170,7 +170,21 @@ __device__ __forceinline__ void pack_rows_body(const uclstm_pack_desc& d, const 
             float v[TAPS];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) v[t] = dwp[pbase + (int64_t)t * per_tap];
-            for (int sl = 1; sl < nslab; ++sl) {          // TAPS independent loads per slab
+            int sl = 1;
+            for (; sl + 3 <= nslab; sl += 3) {            // three slabs = 3 * TAPS independent loads per round trip, added in slab order
+                float a[3][TAPS];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float* ps = dwp + (sl + j) * slab + pbase;
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) a[j][t] = ps[(int64_t)t * per_tap];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) v[t] += a[j][t];
+            }
+            for (; sl < nslab; ++sl) {
                 const float* ps = dwp + sl * slab + pbase;
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) v[t] += ps[(int64_t)t * per_tap];

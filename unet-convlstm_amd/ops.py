@@ -518,8 +518,16 @@ def pack_bias(desc: L.PackDesc, b: torch.Tensor) -> torch.Tensor:
     _dev(b, F32, "bias")
     if desc.n_mode == L.NMODE_IDENTITY and desc.N == desc.n_valid == b.numel() and b.is_contiguous() and b.data_ptr() % 16 == 0:
         return b.detach()          # panel-row order == channel order and no padding rows: the bias IS its panel (no kernel)
+    cache, key = _ACTIVE_CACHE, None
+    if cache is not None and not cache.stale():              # frozen weights (StreamingPredictor): once, like the weight panels
+        key = ("bias", b.data_ptr(), bytes(desc))
+        hit = cache.entries.get(key)
+        if hit is not None and hit[0] == b._version:
+            return hit[1]
     bp = torch.empty((desc.N,), dtype=F32, device=b.device)
     L.check(L.lib.uclstm_pack_bias(C.byref(desc), _p(b), _p(bp), _stream()), "pack_bias")
+    if key is not None:
+        cache.entries[key] = (b._version, bp)
     return bp
 
 
@@ -1022,7 +1030,47 @@ def im2col_first(x: torch.Tensor, time_major: bool) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # conv3x3 (+ optional second source) + BatchNorm + ReLU   (train/unet.py:70-71, :98)
 # ---------------------------------------------------------------------------------------------
-class ConvBNReLU(torch.autograd.Function):
+def _eval_bn_constants(gamma, beta, running_mean, running_var, eps, momentum, Co, Cop) -> torch.Tensor:
+    """[2, 1, Cop] f32 (scale, shift) of an evaluation-mode BatchNorm, folded into the conv epilogue.  Constants of frozen
+    weights: kept in the current PanelCache (StreamingPredictor) like the packed panels, so a rollout frame does not rebuild them."""
+    cache, key, ver = _ACTIVE_CACHE, None, None
+    if cache is not None and not cache.stale():
+        key = ("bn_eval", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps), Cop)
+        ver = (gamma._version, beta._version, running_mean._version, running_var._version)
+        hit = cache.entries.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+    par = torch.empty((2, 1, Cop), dtype=F32, device=gamma.device)
+    L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                     momentum, eps, _p(par[0]), _p(par[1]), None, None, _stream()), "bn_finalize(eval)")
+    if key is not None:
+        cache.entries[key] = (ver, par)
+    return par
+
+
+_OUTER_GRAD = True
+
+
+class _GradAwareFunction(torch.autograd.Function):
+    """Function.forward runs with grad mode off and ctx.needs_input_grad ignores torch.no_grad(): remember the CALLER's grad
+    mode, so that a forward under no_grad (validation, StreamingPredictor) takes the inference kernels, saves nothing and does
+    not count as a use for the data-parallel bucket bookkeeping."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        global _OUTER_GRAD
+        prev, _OUTER_GRAD = _OUTER_GRAD, torch.is_grad_enabled()
+        try:
+            return super(_GradAwareFunction, cls).apply(*args, **kwargs)
+        finally:
+            _OUTER_GRAD = prev
+
+
+def _will_backward(ctx) -> bool:
+    return _OUTER_GRAD and any(ctx.needs_input_grad)
+
+
+class ConvBNReLU(_GradAwareFunction):
     """One (conv3x3 pad 1 + bias -> BatchNorm2d -> ReLU) stage on NHWC bf16.
 
     ``x1`` (optional) is channel-concatenated after ``x0`` and may be smaller, centred by
@@ -1052,7 +1100,7 @@ class ConvBNReLU(torch.autograd.Function):
         bp = pack_bias(pd, bias) if bias is not None else None
         out = torch.empty((n_img, H, W, Cop), dtype=x0.dtype, device=dev)
         K = _k(x0)
-        need_bw = any(ctx.needs_input_grad)
+        need_bw = _will_backward(ctx)
         if training:
             ppg = (n_img // groups) * H * W
             tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups, Cop)
@@ -1100,9 +1148,7 @@ class ConvBNReLU(torch.autograd.Function):
             note_use(weight, gamma, beta, bias)
         else:
             join_forward_side(dev)
-            par = torch.empty((2, 1, Cop), dtype=F32, device=dev)
-            L.check(L.lib.uclstm_bn_finalize(None, 1, 0, Cop, Co, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                             momentum, eps, _p(par[0]), _p(par[1]), None, None, _stream()), "bn_finalize(eval)")
+            par = _eval_bn_constants(gamma, beta, running_mean, running_var, eps, momentum, Co, Cop)
             a = out
             igemm_store(srcs, wp, (H, W), n_img, [(a, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp,
                         col_scale=par[0], col_shift=par[1], relu=True)
@@ -1252,7 +1298,7 @@ class MaxPool2Skip(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # ConvTranspose2d(k=2, s=2)  (train/unet.py:90, :94)
 # ---------------------------------------------------------------------------------------------
-class ConvT2x2(torch.autograd.Function):
+class ConvT2x2(_GradAwareFunction):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _dev(x, ACT, "activation")
@@ -1267,7 +1313,7 @@ class ConvT2x2(torch.autograd.Function):
         igemm_store([SrcView(x)], wp, (h, w), N, segs, ktap=1, pad=0, bias=bp)
         ctx.save_for_backward(x, weight, bias)
         ctx.has_bias = bias is not None
-        if any(ctx.needs_input_grad):
+        if _will_backward(ctx):
             note_use(weight, bias)
         return u
 
@@ -1294,7 +1340,7 @@ class ConvT2x2(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # OutConv 1x1  (train/unet.py:101-107)
 # ---------------------------------------------------------------------------------------------
-class OutConv1x1(torch.autograd.Function):
+class OutConv1x1(_GradAwareFunction):
     """16-bit NHWC in, f32 NCHW out (the model's public output dtype/layout)."""
 
     @staticmethod
@@ -1306,7 +1352,7 @@ class OutConv1x1(torch.autograd.Function):
         L.check(_k(a).uclstm_outconv_fwd(_p(a), _p(weight), _p(bias), _p(y), N, H * W, Cp, Ci, Co, _stream()), "outconv_fwd")
         ctx.save_for_backward(a, weight, bias)
         ctx.has_bias = bias is not None
-        if any(ctx.needs_input_grad):
+        if _will_backward(ctx):
             note_use(weight, bias)
         return y
 
@@ -1337,7 +1383,7 @@ class OutConv1x1(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # SpatialAttention  (train/unet.py:113-125)
 # ---------------------------------------------------------------------------------------------
-class SpatialAttn(torch.autograd.Function):
+class SpatialAttn(_GradAwareFunction):
     """x * sigmoid(conv_kxk([mean_c x, max_c x])) on NHWC 16-bit activations; ``weight`` is the reference's [1,2,k,k] f32."""
 
     @staticmethod
@@ -1355,7 +1401,7 @@ class SpatialAttn(torch.autograd.Function):
                 "attention_fwd")
         ctx.save_for_backward(x, weight, att, desc, arg)
         ctx.channels = channels
-        if any(ctx.needs_input_grad):
+        if _will_backward(ctx):
             note_use(weight)
         return out
 
