@@ -153,7 +153,7 @@ def test_config4_512_rollout_vs_reference(use_graph):
           f"{[round(e, 6) for e in e_ref]}")
     assert max(e_full) <= 2e-3 and max(e_ref) <= 1e-2
     if use_graph:
-        assert sp._graph is not None
+        assert all(g is not None for g in sp._graphs)
 
 
 def test_config0_convlstm_plus_head_vs_reference():

@@ -46,8 +46,11 @@ class ConvLSTMCell(nn.Module):
         self.conv = nn.Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size, padding=padding, bias=bias)
 
     # internal: whole sequence, NHWC
-    def seq_nhwc(self, x_all: Tensor, h0: Optional[Tensor], c0: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    def seq_nhwc(self, x_all: Tensor, h0: Optional[Tensor], c0: Optional[Tensor], out=None) -> Tuple[Tensor, Tensor]:
+        """``out=(h_out, c_out)``: one-step inference writes the new state into these buffers (streaming.StreamingPredictor)."""
         need = _need_grad(x_all, h0, c0, self.conv.weight)
+        if out is not None:
+            return ops.ConvLSTMSeq.apply(x_all, h0, c0, self.conv.weight, self.conv.bias, self.hidden_dim, self.input_dim, need, out)
         return ops.ConvLSTMSeq.apply(x_all, h0, c0, self.conv.weight, self.conv.bias, self.hidden_dim, self.input_dim, need)
 
     def forward(self, x, state=None):
@@ -73,15 +76,16 @@ class ConvLSTM(nn.Module):
         for l in range(num_layers):
             self.layers.append(ConvLSTMCell(input_dim if l == 0 else hidden_dim, hidden_dim, kernel_size))
 
-    def seq_nhwc(self, x_all: Tensor, state: Optional[Sequence]):
-        """x_all bf16 [T,B,H,W,Cp]; state: per layer None or (h bf16 NHWC, c f32 NHWC)."""
+    def seq_nhwc(self, x_all: Tensor, state: Optional[Sequence], out_state: Optional[Sequence] = None):
+        """x_all bf16 [T,B,H,W,Cp]; state: per layer None or (h bf16 NHWC, c f32 NHWC); out_state: per layer (h, c) buffers
+        that receive the new state (one-step inference only)."""
         if state is None:
             state = [None] * len(self.layers)
         out = x_all
         new_states = []
         for li, layer in enumerate(self.layers):
             h0, c0 = (None, None) if state[li] is None else state[li]
-            out, c_T = layer.seq_nhwc(out, h0, c0)
+            out, c_T = layer.seq_nhwc(out, h0, c0, None if out_state is None else out_state[li])
             new_states.append((out[-1], c_T))
         return out, new_states
 
@@ -372,19 +376,22 @@ class TemporalUNetDualView(nn.Module):
 
     # -- streaming: one frame in, one frame out, ALL recurrent states carried (API superset of the reference, whose
     #    forward() drops the skip-LSTM states, train/unet.py:190-191)
-    def step_nhwc(self, x_t: Tensor, full_state: Optional[dict] = None):
+    def step_nhwc(self, x_t: Tensor, full_state: Optional[dict] = None, out_state: Optional[dict] = None):
         """``x_t`` f32 ``[B, 2*in_channels_per_sat, H, W]`` -> ``(y_t f32 [B,out,H,W], full_state)``.
 
         ``full_state`` maps ``'temporal'/'skip3'/'skip2'`` to per-layer ``(h bf16 NHWC, c f32 NHWC)`` lists; ``None`` is the
-        zero state.  Feeding frames one by one reproduces ``forward()`` on the whole sequence, skip LSTMs included."""
+        zero state.  Feeding frames one by one reproduces ``forward()`` on the whole sequence, skip LSTMs included.
+        ``out_state`` (same structure, inference only): buffers the new state is written into -- no copies; h buffers must
+        differ from the input state's, c buffers may be the same tensors."""
         c = self.base_ch
         st = full_state or {}
+        ost = out_state or {}
         xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
-        b_all, st_t = self.temporal.seq_nhwc(xb.unsqueeze(0), st.get("temporal"))
+        b_all, st_t = self.temporal.seq_nhwc(xb.unsqueeze(0), st.get("temporal"), ost.get("temporal"))
         new_state = {"temporal": st_t}
         if self.use_skip_lstm:
-            x3_l, st3 = self.lstm_skip3.seq_nhwc(x3.unsqueeze(0), st.get("skip3"))
-            x2_l, st2 = self.lstm_skip2.seq_nhwc(x2.unsqueeze(0), st.get("skip2"))
+            x3_l, st3 = self.lstm_skip3.seq_nhwc(x3.unsqueeze(0), st.get("skip3"), ost.get("skip3"))
+            x2_l, st2 = self.lstm_skip2.seq_nhwc(x2.unsqueeze(0), st.get("skip2"), ost.get("skip2"))
             x3, x2 = x3_l[0], x2_l[0]
             new_state["skip3"], new_state["skip2"] = st3, st2
         d3 = self.up3.forward_nhwc(b_all[0], x3, c * 8, 1)

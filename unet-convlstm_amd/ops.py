@@ -1438,7 +1438,7 @@ class ConvLSTMSeq(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x_all, h0, c0, weight, bias, Hd, Cx, need_grad):
+    def forward(ctx, x_all, h0, c0, weight, bias, Hd, Cx, need_grad, out=None):
         ctx.set_materialize_grads(False)
         _dev(x_all, ACT, "x_all")
         adt = x_all.dtype
@@ -1449,13 +1449,28 @@ class ConvLSTMSeq(torch.autograd.Function):
         ks = weight.shape[-1]
         pd = lstm_pack_desc(Hd, Cx, ks)
         bp = pack_bias(pd, bias) if bias is not None else None
-        h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=adt, device=dev)
-        c_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=F32, device=dev)
+        if out is not None:
+            # streaming inference: the single step writes the caller's state buffers (h_out must not be h0: the convolution
+            # reads h0's neighbourhoods while h_out is written; c_out may be c0 itself, the cell update is element-wise)
+            if need_grad or T != 1 or h0 is None:
+                raise L.UclstmError("ConvLSTMSeq: out= is for one-step inference with a carried state")
+            for t_, dt_ in ((out[0], adt), (out[1], F32)):
+                if not (t_.is_contiguous() and t_.dtype == dt_ and tuple(t_.shape) == (B, H, W, Hdp)):
+                    raise L.UclstmError("ConvLSTMSeq: out buffers must be contiguous [B,H,W,Hd_p] (h: activation dtype, c: f32)")
+            if out[0].data_ptr() == h0.data_ptr():
+                raise L.UclstmError("ConvLSTMSeq: h_out aliases h0")
+        h_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=adt, device=dev) if out is None else (None, out[0])
+        c_hist = torch.empty((T + 1, B, H, W, Hdp), dtype=F32, device=dev) if out is None else (None, out[1])
+        # inference (nothing saved): step 0 reads the caller's state tensors where they lie instead of copies in slot 0
+        direct = (not need_grad and h0 is not None and h0.is_contiguous() and h0.dtype == adt and tuple(h0.shape) == (B, H, W, Hdp)
+                  and (c0 is None or (c0.is_contiguous() and c0.dtype == F32 and tuple(c0.shape) == (B, H, W, Hdp))))
+        if out is not None and not direct:
+            raise L.UclstmError("ConvLSTMSeq: out= needs the carried state as contiguous [B,H,W,Hd_p] tensors (h: activation dtype, c: f32)")
         if h0 is None:
             h_hist[0].zero_()
-        else:
+        elif not direct:
             h_hist[0].copy_(h0)
-        if c0 is not None:
+        if c0 is not None and not direct:
             c_hist[0].copy_(c0)
         gates = torch.empty((T, B, H, W, 4, Hdp), dtype=adt, device=dev) if need_grad else None
         pixels = B * H * W
@@ -1481,10 +1496,11 @@ class ConvLSTMSeq(torch.autograd.Function):
         nsl = ksplit_used(wp.shape[1], ksplit) if ksplit > 1 else 0
         pre = torch.empty((nsl, pixels, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
-            c_prev = c_hist[t] if (c0 is not None or t > 0) else None
+            c_prev = (c0 if (direct and t == 0) else c_hist[t]) if (c0 is not None or t > 0) else None
+            h_prev = h0 if (direct and t == 0) else h_hist[t]
             g_t = gates[t] if need_grad else None
             px_t = pre_x[t] if hoist else None
-            srcs = ([] if hoist else [SrcView(x_all[t])]) + [SrcView(h_hist[t])]
+            srcs = ([] if hoist else [SrcView(x_all[t])]) + [SrcView(h_prev)]
             if hoist and t == 0 and h0 is None:
                 # zero initial state (train/unet.py:23-25): W_h * 0 = 0, the step is the point-wise update of W_x * x_0
                 L.check(K.uclstm_lstm_fwd_pointwise(None, 0, 0, 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[1]), _p(h_hist[1]),
@@ -1494,11 +1510,13 @@ class ConvLSTMSeq(torch.autograd.Function):
                 L.check(K.uclstm_lstm_fwd_pointwise(_p(pre), nsl, pre.stride(0), 0, _p(px_t), _p(bp), _p(c_prev), _p(c_hist[t + 1]),
                                                         _p(h_hist[t + 1]), _p(g_t), pixels, Hdp, _stream()), "lstm_fwd_pointwise")
             else:
-                igemm_lstm(None if hoist else x_all[t], h_hist[t], wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks, pre_add=px_t)
+                igemm_lstm(None if hoist else x_all[t], h_prev, wp, bp, c_prev, c_hist[t + 1], h_hist[t + 1], g_t, ks, pre_add=px_t)
         if need_grad:
             ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates, bias)
             ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, ks)
             note_use(weight, bias)
+        if out is not None:
+            return out[0].unsqueeze(0), out[1]
         return h_hist[1:], c_hist[T]
 
     @staticmethod
