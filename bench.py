@@ -173,6 +173,22 @@ def rollout_bench(a, U, dev, skip):
            "finite": bool(torch.isfinite(y).all())}
     if fwd_gf:
         out["model_tflops"] = round(out["value"] * fwd_gf / 1e3, 2)
+    if a.dump_launches:
+        # one eager frame with HIP events around every GEMM launch (what the graph replays)
+        from unet_convlstm_amd import ops
+        eager = U.StreamingPredictor(model, use_graph=False)
+        for i in range(3):
+            eager.step(frames[i % 4])
+        ops.PROFILE = []
+        eager.step(frames[3])
+        torch.cuda.synchronize()
+        rows, ops.PROFILE = ops.PROFILE, None
+        tot = 0.0
+        for kind, flops, e0, e1, note in rows:
+            t_ms = e0.elapsed_time(e1)
+            tot += t_ms
+            log(f"{kind:32s} {t_ms * 1e3:8.1f} us {flops / t_ms / 1e9:7.1f} TF/s  {note}")
+        log(f"GEMM launches of one frame: {tot * 1e3:.1f} us")
     print(json.dumps(out), flush=True)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 10
+#define UCLSTM_ABI_VERSION 11
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -261,6 +261,14 @@ int32_t uclstm_maxpool2_fwd(const void* a, void* p, int32_t n_img, int32_t H, in
 int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, const void* add, void* da, int32_t n_img, int32_t H, int32_t W, int32_t Cp,
                             void* stream);
 
+/* Finish of a split-K convolution with the STORE epilogue: out[pixel][c] = act16(relu?((sum of the nslab f32 slabs
+ * pre[s*slab + pixel*ld + c] + bias[c]) * col_scale[c] + col_shift[c])), c < C (C % 8 == 0, ld >= C) -- the expression of
+ * uclstm_igemm_fwd's own epilogue.  For inference convolutions on few pixels (a 32 x 32 bottleneck is 32 tiles on 256 CUs): the
+ * GEMM runs as UCLSTM_EPI_ATOMIC K ranges in slab mode and this kernel applies bias / folded BatchNorm / ReLU
+ * (train/unet.py:70-71 in eval mode). */
+int32_t uclstm_splitk_finish(const float* pre, int32_t nslab, int64_t slab, int32_t ld, const float* bias, const float* col_scale,
+                             const float* col_shift, int32_t relu, void* out, int64_t pixels, int32_t C, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* ConvLSTM backward point-wise part (autograd of train/unet.py:29-35)                  */
 /* ------------------------------------------------------------------------------------ */
@@ -396,6 +404,7 @@ UCLSTM_F16_TWIN(uclstm_maxpool2_fwd)
 UCLSTM_F16_TWIN(uclstm_maxpool2_bwd)
 UCLSTM_F16_TWIN(uclstm_lstm_bwd_pointwise)
 UCLSTM_F16_TWIN(uclstm_lstm_fwd_pointwise)
+UCLSTM_F16_TWIN(uclstm_splitk_finish)
 UCLSTM_F16_TWIN(uclstm_nchw_to_nhwc)
 UCLSTM_F16_TWIN(uclstm_nhwc_to_nchw)
 UCLSTM_F16_TWIN(uclstm_nchw_grad_to_nhwc)

@@ -833,3 +833,47 @@ def test_convlstm_5x5_and_7x7_gate_convolutions_golden(k):
         check_f32(v.grad.cpu(), g["g/" + n], f"ConvLSTM k={k} grad " + n, l2=3e-2)
     with pytest.raises(U.UclstmError):
         U.ConvLSTMCell(4, 8, kernel_size=4)
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,dtype", [(1, 256, 256, 16, 16, "bf16"), (1, 512, 136, 8, 8, "bf16"), (2, 128, 128, 8, 12, "f16")])
+def test_split_k_store_convolution_equals_the_single_pass(N, Ci, Co, H, W, dtype):
+    """Inference convolutions on few pixels run as K ranges + uclstm_splitk_finish (bias, folded BatchNorm, ReLU): against the
+    one-pass kernel the f32 sums differ only in their association, so after rounding to 16 bits almost every element is
+    identical and none differs by more than one unit in the last place; and against the f32 convolution."""
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    torch.manual_seed(31)
+    x = torch.randn(N, Ci, H, W).to(dt).float()
+    w = (torch.randn(Co, Ci, 3, 3) * 0.05).to(dt).float()
+    b, sc, sh = torch.randn(Co), torch.rand(Co) + 0.5, torch.randn(Co) * 0.3
+    xa = torch.zeros(N, H, W, cpad(Ci))
+    xa[..., :Ci] = x.permute(0, 2, 3, 1)
+    xa = xa.to(dt).to(DEV).contiguous()
+    pd = ops.conv_pack_desc(Co, Ci, [Ci], [cpad(Ci)])
+    wp = ops.pack_weights(pd, w.to(DEV), 0, dt)
+    Cop = cpad(Co)
+    pad = lambda v: torch.cat([v, torch.zeros(Cop - Co)]).to(DEV)   # noqa: E731
+    bp, scp, shp = pad(b), pad(sc), pad(sh)
+    outs = {}
+    ops.KERNEL_LOG = []
+    try:
+        for split in (True, False):
+            ops.SPLITK_STORE = split
+            out = torch.full((N, H, W, Cop), 7.0, dtype=dt, device=DEV)
+            ops.igemm_store([ops.SrcView(xa)], wp, (H, W), N, [(out, 0, Cop, 0, 1, 0, 0)], ktap=3, pad=1, bias=bp, col_scale=scp,
+                            col_shift=shp, relu=True)
+            outs[split] = out
+        epis = [e for e, _ in ops.KERNEL_LOG]
+    finally:
+        ops.SPLITK_STORE = True
+        ops.KERNEL_LOG = None
+    assert epis == [U._lib.EPI_ATOMIC, U._lib.EPI_STORE], epis            # the first call really took the split-K path
+    a, c = outs[True].float(), outs[False].float()
+    ulp = 2.0 ** (-7 if dtype == "bf16" else -10)
+    diff = (a - c).abs()
+    assert bool((diff <= ulp * c.abs().clamp_min(2.0 ** -10) * 1.01).all()), float(diff.max())
+    frac = float((diff > 0).float().mean())
+    print(f"[parity] split-K store vs one pass ({dtype}): {frac:.4%} of elements differ (by one unit in the last place)")
+    assert frac <= 0.02
+    ref = torch.relu((F.conv2d(x, w, b, padding=1)) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    check_bf16(from_nhwc(outs[True], Co), ref, "split-K conv + folded BN + ReLU", l2=4e-3 if dtype == "bf16" else 6e-4, mx=2e-2)
+    assert pad_is_zero(outs[True], Co)

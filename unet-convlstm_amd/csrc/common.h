@@ -13,6 +13,7 @@
 #define uclstm_igemm_wgrad uclstm_igemm_wgrad_f16
 #define uclstm_pack_weights uclstm_pack_weights_f16
 #define uclstm_pack_weights_batched uclstm_pack_weights_batched_f16
+#define uclstm_splitk_finish uclstm_splitk_finish_f16
 #define uclstm_bn_apply_relu uclstm_bn_apply_relu_f16
 #define uclstm_bn_bwd_reduce uclstm_bn_bwd_reduce_f16
 #define uclstm_bn_bwd_apply uclstm_bn_bwd_apply_f16

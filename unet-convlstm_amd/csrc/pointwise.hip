@@ -1195,6 +1195,54 @@ extern "C" int32_t uclstm_maxpool2_bwd(const void* a, const void* dp, const void
     return UCLSTM_OK;
 }
 
+namespace {
+// Finish of a split-K convolution with the STORE epilogue (inference on few pixels: a 32 x 32 bottleneck gives 32 tiles for 256
+// CUs, so the GEMM runs as K ranges that store f32 partial tiles): out = act16(relu?((sum of slabs + bias) * scale + shift)),
+// the same expression, in the same order, as the GEMM's own epilogue.  Thread = 8 channels of a pixel.
+__global__ void splitk_finish_kernel(const float* __restrict__ pre, int nslab, int64_t slab, int ld, const float* __restrict__ bias,
+                                     const float* __restrict__ scale, const float* __restrict__ shift, int relu, uint4* __restrict__ out,
+                                     int64_t chunks, FastDiv dcpc) {
+    const int cpc = dcpc.d;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+        const uint32_t p = fdiv((uint32_t)idx, dcpc);
+        const uint32_t cc = (uint32_t)idx - p * cpc;
+        const float* src = pre + (int64_t)p * ld + cc * 8;
+        float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4);
+        for (int sl = 1; sl < nslab; ++sl) {
+            const float4 t0 = *(const float4*)(src + sl * slab), t1 = *(const float4*)(src + sl * slab + 4);
+            a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+            a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+        }
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float bs[8], sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bs[i] = bias ? bias[cc * 8 + i] : 0.f;
+            sc[i] = scale ? scale[cc * 8 + i] : 1.f;
+            sh[i] = shift ? shift[cc * 8 + i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float x = (v[i] + bs[i]) * sc[i] + sh[i];
+            if (relu) x = fmaxf(x, 0.f);
+            v[i] = x;
+        }
+        out[idx] = pack8(v);
+    }
+}
+}  // namespace
+
+extern "C" int32_t uclstm_splitk_finish(const float* pre, int32_t nslab, int64_t slab, int32_t ld, const float* bias, const float* col_scale,
+                                        const float* col_shift, int32_t relu, void* out, int64_t pixels, int32_t C, void* stream) {
+    if (!pre || !out || !aligned16(pre) || !aligned16(out) || nslab < 1 || pixels <= 0 || C <= 0 || (C % 8) || ld < C || (ld % 4)) return UCLSTM_E_BADARG;
+    if (nslab > 1 && (slab < pixels * ld || (slab % 4))) return UCLSTM_E_BADARG;
+    const int64_t chunks = pixels * (C / 8);
+    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(splitk_finish_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, ld, bias, col_scale, col_shift,
+                  relu, (uint4*)out, chunks, make_fastdiv(C / 8));
+    return UCLSTM_OK;
+}
+
 extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t slab, int32_t clear, const float* pre_add, const float* bias,
                                              const float* c_prev, float* c_out, void* h_out, void* gates_out, int64_t pixels, int32_t Hd_p,
                                              void* stream) {

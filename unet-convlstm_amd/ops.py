@@ -740,6 +740,12 @@ def _same_act_dtype(tensors, what: str) -> None:
         raise L.UclstmError(f"{what}: activations, panels and outputs must share one 16-bit dtype, got {[str(t.dtype) for t in tensors]}")
 
 
+# Split-K for STORE-epilogue convolutions whose tile grid cannot fill the chip (no BatchNorm statistics wanted: inference, or
+# evaluation-mode statistics): below SPLITK_STORE_BELOW 128 x 128 tiles.  UCLSTM_SPLITK_STORE=0 switches it off.
+SPLITK_STORE = os.environ.get("UCLSTM_SPLITK_STORE", "1") != "0"
+SPLITK_STORE_BELOW = int(os.environ.get("UCLSTM_SPLITK_STORE_BELOW", "192"))
+
+
 def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, segs, *, ktap: int, scale: int = 1,
                 pad: int = 0, groups: int = 1, bias=None, col_scale=None, col_shift=None, relu: bool = False, stats=None) -> None:
     """segs: list of (tensor, n_begin, n_end, c_off, scale, oy, ox).  ``stats``: [groups, tiles_per_group, N, 2]."""
@@ -755,6 +761,20 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
                         groups=(i1 - i0) // ipg if stats is not None else 1, bias=bias, col_scale=col_scale, col_shift=col_shift,
                         relu=relu, stats=sub_stats)
         return
+    if stats is None and SPLITK_STORE and scale == 1 and len(segs) == 1:
+        # few output pixels (batch-1 inference: a 32 x 32 bottleneck is 4 x 8 tiles for 256 CUs): K ranges store f32 partial
+        # tiles, uclstm_splitk_finish applies the epilogue.  Only for one dense destination (a plain convolution).
+        t, n_begin, n_end, c_off, sg_scale, oy, ox = (tuple(segs[0]) + (0, 1, 0, 0))[:7]
+        N, pixels = wp.shape[0], n_img * out_hw[0] * out_hw[1]
+        if (n_begin, n_end, c_off, sg_scale, oy, ox) == (0, N, 0, 1, 0, 0) and t.is_contiguous() and tuple(t.shape) == (n_img, out_hw[0], out_hw[1], N):
+            ksplit = split_k_factor(pixels, N, wp.shape[1] // 64, min_blocks=SPLITK_STORE_BELOW)
+            if ksplit > 1:
+                nsl = ksplit_used(wp.shape[1], ksplit)
+                pre = torch.empty((nsl, pixels, N), dtype=F32, device=t.device)
+                igemm_atomic(srcs, wp, out_hw, n_img, pre, ksplit, ktap=ktap, pad=pad, slabs=True, kind="igemm_fwd_store_splitk")
+                L.check(_k(wp).uclstm_splitk_finish(_p(pre), nsl, pre.stride(0), N, _p(bias), _p(col_scale), _p(col_shift), int(relu), _p(t),
+                                                    pixels, N, _stream()), "splitk_finish")
+                return
     d = L.IgemmDesc()
     d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], groups
     d.ktap, d.scale, d.pad, d.nsrc = ktap, scale, pad, len(srcs)
