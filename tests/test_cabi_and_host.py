@@ -405,3 +405,32 @@ def test_panel_cache_is_owned_and_invalidated_by_weight_updates():
     c.clear()
     assert not c.stale()
     assert not hasattr(ops, "_PANEL_CACHE")                # no module-global cache any more
+
+
+def test_pack_job_table_families_and_segments():
+    """Host side of the batched look-ahead packing: uclstm_pack_job_init (a host function) classifies a panel into its kernel
+    family and sizes its block range as the single-panel launch would; ops.pack_segments cuts the panels into segments at
+    cumulative byte fractions."""
+    import ctypes as C
+    cases = [(ops.conv_pack_desc(72, 80, [56, 24], [56, 24]), 1, (1 + 1) * 72),               # rows, 9 taps: (chunks0 + chunks1) x N
+             (ops.lstm_pack_desc(40, 24), 1, None),
+             (ops.convt_dgrad_pack_desc(48, 24), 2, None),                                    # rows, 4 taps
+             (ops.conv_dgrad_pack_desc(200, 136, 136), 3, ((200 + 63) // 64) * ((136 + 15) // 16)),   # transposed: 64 K columns x 16 rows
+             (ops.lstm_dgrad_pack_desc(40, 24, 40), 3, None),
+             (ops.convt_pack_desc(48, 24), 0, None)]                                          # generic
+    w = (C.c_float * 4)()
+    for d, family, nblocks in cases:
+        job = L.PackJob()
+        rc = L.lib.uclstm_pack_job_init(C.byref(job), C.byref(d), C.cast(w, C.c_void_p), C.cast(w, C.c_void_p), 5)
+        assert rc == family == job.family, (rc, family)
+        assert job.block0 == 5 and job.nblocks >= 1 and job.gx >= 1 and job.nblocks % job.gx == 0
+        if nblocks is not None:
+            assert job.nblocks == nblocks, (job.nblocks, nblocks)
+        assert bytes(job.d) == bytes(d) and job.div[2] == d.Ktot
+    assert L.lib.uclstm_pack_job_init(None, C.byref(cases[0][0]), C.cast(w, C.c_void_p), C.cast(w, C.c_void_p), 0) == -1
+    assert L.lib.uclstm_pack_job_init(C.byref(L.PackJob()), C.byref(cases[0][0]), None, C.cast(w, C.c_void_p), 0) == -1
+    sizes = [1, 1, 8, 10, 30, 50]
+    assert ops.pack_segments(sizes, (0.02, 0.2, 0.5)) == [0, 0, 1, 1, 2, 3]
+    assert ops.pack_segments(sizes, ()) == [0] * 6
+    seg = ops.pack_segments([7] * 40, ops.PACK_SEGMENTS)
+    assert seg[0] == 0 and seg == sorted(seg) and seg[-1] == len(ops.PACK_SEGMENTS)

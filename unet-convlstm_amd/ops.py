@@ -367,6 +367,16 @@ PACK_BATCHED = os.environ.get("UCLSTM_PACK_BATCHED", "1") != "0"
 PACK_SEGMENTS = tuple(float(x) for x in os.environ.get("UCLSTM_PACK_SEGMENTS", "0.02,0.08,0.2,0.35,0.5,0.65,0.8").split(",") if x)
 
 
+def pack_segments(sizes: Sequence[int], fractions: Sequence[float]) -> List[int]:
+    """Segment index of every panel (in order of first use): panel i belongs to segment s when the bytes BEFORE it have
+    reached ``fractions[s - 1]`` of the total (and not yet ``fractions[s]``); non-decreasing, segment 0 is never empty."""
+    total, run, seg_of = float(sum(sizes)), 0, []
+    for sz in sizes:
+        seg_of.append(sum(1 for f in fractions if run >= f * total))
+        run += sz
+    return seg_of
+
+
 class _PackBatch:
     """All look-ahead panels of a step as a few launches per kernel family (uclstm_pack_weights_batched).
 
@@ -384,11 +394,7 @@ class _PackBatch:
         self.sig = tuple(key for key, _, _, _ in items)
         self.panels, self.keep, self.segments = {}, [], []            # segments: [[(dtype, fam, byte offset, njobs, blocks)]]
         dev = items[0][2].device
-        sizes = [desc.N * desc.Ktot for _, desc, _, _ in items]
-        total, run, seg_of = float(sum(sizes)), 0, []
-        for sz in sizes:
-            seg_of.append(sum(1 for f in PACK_SEGMENTS if run >= f * total))
-            run += sz
+        seg_of = pack_segments([desc.N * desc.Ktot for _, desc, _, _ in items], PACK_SEGMENTS)
         jobs_all = []
         for n, seg in enumerate(sorted(set(seg_of))):
             groups: dict = {}
