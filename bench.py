@@ -246,17 +246,27 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     torch.cuda.synchronize()
+    # The timed region starts from a synchronised host: a generation-2 garbage collection (~75 ms of host time in a process
+    # that has imported torch) in its first steps is not hidden by run-ahead and showed up as ONE 60-130 ms step in ~40 % of
+    # 20-30-step runs (tools/spike_hunt.py).  Collect now and freeze what is alive, as a training loop does after its first
+    # steps (engine.train_one_epoch); nothing of the step's GPU work is skipped.
+    U.quiesce_host_gc()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # one event record per step: no synchronisation
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss, _ = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    log(f"per-step device time: min {per_step[0]:.2f}  median {per_step[len(per_step) // 2]:.2f}  max {per_step[-1]:.2f} ms")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,6 +275,10 @@ def main():
     value = frames / dt
     log(f"timed {a.steps} steps in {dt:.3f} s")
     lossv = float(loss)
+    # does the weight-gradient stream still run beside the main stream?  (the runtime maps streams to hardware queues; two on one
+    # queue serialise, which costs this step ~2.5 ms: recorded so that a slow run can be told from a slow box)
+    side = ops.side_stream(dev)
+    overlap = {"probes": ops._SIDE_STREAM_PROBES.get(str(dev)), "still_concurrent": bool(ops._streams_overlap(torch.cuda.current_stream(dev), side))}
 
     roof = None
     if not a.no_roofline:
@@ -348,7 +362,8 @@ def main():
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             **({"rehearsal": "all ranks on cuda:0, collectives over gloo -- not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
-            "final_loss": round(lossv, 5),
+            "final_loss": round(lossv, 5), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
+            "step_ms_min_median_max": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)],
         }
         if gf is not None:
             out["model_tflops"] = round(value * gf / 1e3, 2)

@@ -236,13 +236,30 @@ class _Metrics:
         return a / n, math.sqrt(q / n), e / n
 
 
+def quiesce_host_gc() -> None:
+    """Collect once and move every object alive now into the permanent generation (``gc.freeze``).
+
+    A training step is ~500 kernel launches from Python; the host runs 1-3 steps ahead of the device.  A full (generation 2)
+    garbage collection of a process that has imported torch walks ~10^6 objects and stops the host for ~75 ms (measured,
+    ``tools/spike_hunt.py``): whenever the host is less than that ahead -- after any synchronisation: the start of an epoch,
+    a ``loss.item()``, a benchmark's timed region -- the device runs dry and ONE step takes 60-130 ms instead of 33.  After
+    ``gc.freeze()`` later collections only walk objects created since, which takes microseconds.  Call it once the model,
+    the optimiser and the first steps' caches exist; ``train_one_epoch`` does after its second step.
+    """
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def train_one_epoch(model, loader, optimizer, device, dataset_obj, use_mask=True, ddp=None):
     """Reference main.py:77-144; returns ``(avg_loss, avg_mae, avg_rmse, avg_me)``."""
     model.train()
     total = torch.zeros((), dtype=torch.float64, device=device)
     n = 0
     met = _Metrics(device)
-    for x, y, mask in loader:
+    for it, (x, y, mask) in enumerate(loader):
+        if it == 2:
+            quiesce_host_gc()
         x, y, mask = x.to(device, non_blocking=True), y.to(device, non_blocking=True), mask.to(device, non_blocking=True)
         loss, y_pred = train_step(model, optimizer, x, y, mask, use_mask, ddp)
         total += loss.double() * x.size(0)
