@@ -158,6 +158,7 @@ def rollout_bench(a, U, dev, skip):
     for i in range(max(a.warmup, 3)):                 # eager warm-up + capture + first replay
         sp.step(frames[i % 4])
     torch.cuda.synchronize()
+    U.quiesce_host_gc()                               # a 75-ms garbage collection would be 60 frames of this host-paced loop
     n = a.steps * a.seq
     t0 = time.perf_counter()
     for i in range(n):
