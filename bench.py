@@ -363,7 +363,7 @@ def main():
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             **({"rehearsal": "all ranks on cuda:0, collectives over gloo -- not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
-            "final_loss": round(lossv, 5), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
+            "final_loss": round(lossv, 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
             "step_ms_min_median_max": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)],
         }
         if gf is not None:
