@@ -832,6 +832,16 @@ __global__ void colsum_kernel(const uint4* __restrict__ a, float* __restrict__ o
     if (act) {
         const int64_t st = cg.rows;
         int64_t p = p0 + prow;
+        for (; p + 7 * st < p1; p += 8 * st) {                     // eight 16-byte loads in flight (a pure-read kernel: ~3.9 TB/s is the ceiling)
+            uint4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = a[(p + u * st) * cg.cpc + cc];
+            float v[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) unpack8(q[u], v[u]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + ((v[4][i] + v[5][i]) + (v[6][i] + v[7][i]));
+        }
         for (; p + 3 * st < p1; p += 4 * st) {
             const uint4 q0 = a[p * cg.cpc + cc], q1 = a[(p + st) * cg.cpc + cc], q2 = a[(p + 2 * st) * cg.cpc + cc],
                         q3 = a[(p + 3 * st) * cg.cpc + cc];
@@ -1387,9 +1397,9 @@ extern "C" int32_t uclstm_colsum(const void* a, float* out, int64_t pixels, int3
     if (!aligned16(a) || !out || pixels <= 0 || Cp <= 0 || (Cp % 8)) return UCLSTM_E_BADARG;
     const ColGeom cg = col_geom(Cp);
     const int ncg = (cg.cpc + NT - 1) / NT;                    // column groups (grid.y)
-    // ~2048 blocks in all (8 per CU), but at least 16 pixels per thread row so that the atomic tail stays small
+    // ~2048 blocks in all (8 per CU), but at least 32 pixels per thread row (four rounds of eight loads; small atomic tail)
     int64_t nb = 2048 / ncg;
-    const int64_t maxb = (pixels + 16 * cg.rows - 1) / (16 * cg.rows);
+    const int64_t maxb = (pixels + 32 * cg.rows - 1) / (32 * cg.rows);
     if (nb > maxb) nb = maxb;
     if (nb < 1) nb = 1;
     const int64_t ppb = (pixels + nb - 1) / nb;
