@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 11
+#define UCLSTM_ABI_VERSION 12
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -418,6 +418,9 @@ UCLSTM_F16_TWIN(uclstm_attention_bwd)
 /* Library self-description (used by the loader to check the build). */
 int32_t uclstm_abi_version(void);
 const char* uclstm_build_arch(void);
+/* SHA-256 (hex) of the sources the library was built from: csrc/*, this header and the compiler flags
+ * (unet-convlstm_amd/build.py: source_hash).  The loader refuses a library whose hash differs from the tree's. */
+const char* uclstm_source_hash(void);
 /* hipGetErrorString of the most recent launch that returned UCLSTM_E_LAUNCH. */
 const char* uclstm_last_error_string(void);
 

@@ -41,6 +41,54 @@ def test_library_exports_every_header_symbol():
     assert L.lib.uclstm_build_arch() == b"gfx950"
 
 
+def test_library_reports_the_sources_of_this_tree():
+    """Ship exactly what is tracked: the loaded library was built from csrc/*, include/uclstm.h and build.py's flags as they are
+    in this tree (the loader would have refused it otherwise), and the sidecar binds that hash to this very file."""
+    from unet_convlstm_amd import build as B
+    assert L.lib.uclstm_source_hash().decode() == B.source_hash()
+    assert B.library_hash(L.LIB_PATH) == B.source_hash() and not B.needs_rebuild()
+    stray = [f for f in os.listdir(os.path.join(ROOT, "unet-convlstm_amd", "build")) if f.endswith(".so") or "whatif" in f] \
+        if os.path.isdir(os.path.join(ROOT, "unet-convlstm_amd", "build")) else []
+    assert not stray, f"stale A/B builds would ship to the GPU box: {stray} (keep them under unet-convlstm_amd/ab/)"
+
+
+def test_build_recompiles_when_a_source_byte_changes(tmp_path):
+    """build() decides by content hash, not by mtime: an edited source byte (with the old mtime restored) recompiles, an
+    untouched tree does not, and a library next to a foreign sidecar counts as stale."""
+    from unet_convlstm_amd import build as B
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    hdr = tmp_path / "api.h"
+    hdr.write_text("int probe_value(void);\n")
+    src = csrc / "probe.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n__global__ void k(int* p) { *p = 1; }\nextern "C" int probe_value(void) { return 41; }\n')
+    lib = str(tmp_path / "libprobe.so")
+    kw = dict(csrc=str(csrc), header=str(hdr), lib=lib, sources=["probe.hip"], f16_sources=[], verbose=False)
+    B.build(**kw)
+    h0 = B.source_hash(str(csrc), str(hdr), ["probe.hip"], [])
+    so = C.CDLL(lib)
+    so.uclstm_source_hash.restype = C.c_char_p
+    assert so.uclstm_source_hash().decode() == h0 == B.library_hash(lib) and so.probe_value() == 41
+    t_lib, t_obj = os.path.getmtime(lib), os.path.getmtime(tmp_path / "build" / "probe.o")
+    B.build(**kw)                                                    # nothing changed: nothing rebuilt
+    assert os.path.getmtime(lib) == t_lib and os.path.getmtime(tmp_path / "build" / "probe.o") == t_obj
+    st = os.stat(src)
+    src.write_text(src.read_text().replace("return 41", "return 42"))
+    os.utime(src, (st.st_atime, st.st_mtime))                        # an mtime-based check would not see this edit
+    assert B.needs_rebuild(lib, str(csrc), str(hdr), ["probe.hip"], [])
+    B.build(**kw)
+    h1 = B.source_hash(str(csrc), str(hdr), ["probe.hip"], [])
+    assert h1 != h0 and B.library_hash(lib) == h1
+    lib2 = str(tmp_path / "libprobe2.so")                            # dlopen caches by path: load the rebuilt file under a new name
+    os.link(lib, lib2)
+    so2 = C.CDLL(lib2)
+    so2.uclstm_source_hash.restype = C.c_char_p
+    assert so2.uclstm_source_hash().decode() == h1 and so2.probe_value() == 42
+    with open(lib, "ab") as f:                                       # a library that is not the one the sidecar describes
+        f.write(b"\0")
+    assert B.library_hash(lib) is None and B.needs_rebuild(lib, str(csrc), str(hdr), ["probe.hip"], [])
+
+
 def test_struct_layouts_match_the_header():
     # sizes follow from the header's field lists (natural alignment, 8-byte pointers)
     assert C.sizeof(L.Src) == 32

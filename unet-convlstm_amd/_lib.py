@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -133,9 +133,10 @@ _PROTOS = {
     "uclstm_stream_spin": [_I, _P],
     "uclstm_abi_version": [],
     "uclstm_build_arch": [],
+    "uclstm_source_hash": [],
     "uclstm_last_error_string": [],
 }
-_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64}
+_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_source_hash": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64}
 
 
 # entry points that exist twice: name (bfloat16) and name_f16 (IEEE binary16), identical signatures (include/uclstm.h)
@@ -167,6 +168,13 @@ def _load() -> C.CDLL:
             fn.restype = _RESTYPES.get(name, C.c_int32)
     if lib.uclstm_abi_version() != ABI_VERSION:
         raise UclstmError("libuclstm.so ABI version mismatch; rebuild the library")
+    if not os.environ.get("UCLSTM_LIB"):
+        # ship exactly what is tracked: the library says which sources it was built from (build.py: source_hash)
+        from . import build as _build
+        built, tree = lib.uclstm_source_hash().decode(), _build.source_hash()
+        if built != tree:
+            raise UclstmError(f"{LIB_PATH} was built from other sources than this tree (library {built[:16]}, tree {tree[:16]}): "
+                              "run `python unet-convlstm_amd/build.py`")
     return lib
 
 

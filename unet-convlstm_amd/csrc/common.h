@@ -51,10 +51,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Launch and report only THIS launch's error: the per-thread "last error" may hold a stale, already
 // handled code from another library's HIP call (observed: a launch right after torch's own copies).
-#if defined(UCLSTM_ACT_F16)
-#define g_uclstm_last_hip_error g_uclstm_last_hip_error_f16_
-#endif
-inline int g_uclstm_last_hip_error = 0;      // hipError_t of the most recent failed launch (diagnostics)
+inline int g_uclstm_last_hip_error = 0;      // hipError_t of the most recent failed launch (diagnostics); ONE variable for both compile passes
 #define UCLSTM_LAUNCH(...)                                      \
     do {                                                        \
         (void)hipGetLastError();                                \
