@@ -24,7 +24,7 @@ import subprocess
 import sys
 import time
 
-import torch
+torch = None          # imported by main() AFTER the launcher branch: the parent that starts the ranks never loads torch at all
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -43,7 +43,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU (main.py:215)")
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU (main.py:215); weak scaling keeps it fixed as N grows")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): per-GPU batch = --batch on every rank; strong: --global-batch sequences in total, "
+                         "per-GPU batch = global / N (SURVEY.md 8e: global 32 -> 4 per GPU at N = 8)")
+    ap.add_argument("--global-batch", type=int, default=32, help="total sequences per step with --scaling strong")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second north_star workload (cloud 128x128 seq-8, same per-GPU batch) that follows the headline")
     ap.add_argument("--seq", type=int, default=20)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--base-ch", type=int, default=64)
@@ -77,14 +83,36 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs (sysfs), cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when sysfs says nothing (then the ranks
+    themselves report a missing device)."""
+    n = None
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        n = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            k = len([x for x in v.split(",") if x.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
 def self_launch(a) -> int:
     """``python bench.py --gpus N`` without torchrun: start the N ranks HERE, as fresh child processes, before this process
     has made any HIP call (a process that has initialised the GPU must never exec or fork into another GPU program), and
     return the launcher's exit code.  The children are this same script under ``torch.distributed.run``; rank 0 prints the
     JSON line on the inherited stdout."""
     if not a.dry_launch:
-        have = torch.cuda.device_count()          # counts devices without creating a HIP context
-        if have < a.gpus and not (a.rehearse_on_one_gpu and have >= 1):
+        have = visible_gpu_count()                # sysfs + environment only: no torch, no HIP call in this process
+        if have is not None and have < a.gpus and not (a.rehearse_on_one_gpu and have >= 1):
             print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
@@ -102,12 +130,13 @@ def dry_launch(a, world: int, rank: int) -> None:
     if world > 1:
         dist.init_process_group("gloo")
         seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "world_size": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+        dist.all_gather_object(seen, {"rank": rank, "world_size": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                                      "per_gpu_batch": a.batch})
         dist.destroy_process_group()
     else:
-        seen = [{"rank": 0, "world_size": 1, "local_rank": 0}]
+        seen = [{"rank": 0, "world_size": 1, "local_rank": 0, "per_gpu_batch": a.batch}]
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": a.gpus, "ranks": seen}), flush=True)
+        print(json.dumps({"dry_launch": True, "n_gpus": a.gpus, "scaling": a.scaling, "global_batch": a.batch * world, "ranks": seen}), flush=True)
 
 
 def cpu_baseline(base_ch: int, skip: bool, size: int, seq: int):
@@ -185,7 +214,7 @@ def rollout_bench(a, U, dev, skip):
         torch.cuda.synchronize()
         rows, ops.PROFILE = ops.PROFILE, None
         tot = 0.0
-        for kind, flops, e0, e1, note in rows:
+        for kind, flops, e0, e1, note, _nb in rows:
             t_ms = e0.elapsed_time(e1)
             tot += t_ms
             log(f"{kind:32s} {t_ms * 1e3:8.1f} us {flops / t_ms / 1e9:7.1f} TF/s  {note}")
@@ -193,15 +222,160 @@ def rollout_bench(a, U, dev, skip):
     print(json.dumps(out), flush=True)
 
 
+def run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, *, size, seq, batch, steps, warmup, roofline, tag):
+    """Warm up, time ``steps`` training steps of one workload (barrier + synchronize on both sides, MAX over ranks) and, when
+    asked, price one extra instrumented step against the MFMA / HBM rooflines.  Returns a dict of measurements."""
+    skip = not a.no_skip_lstm
+    data = U.SyntheticSequences(batch, seq, size, size, seed=1 + rank, kind="uniform", device=dev)
+    x, y = data.x, data.y
+
+    def step():
+        return U.train_step(model, opt, x, y, None, False, ddp)      # USE_MASK = False, main.py:219
+
+    for i in range(warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"{tag}: warm-up step {i} done")
+    torch.cuda.synchronize()
+    # The timed region starts from a synchronised host: a generation-2 garbage collection (~75 ms of host time in a process
+    # that has imported torch) in its first steps is not hidden by run-ahead and showed up as ONE 60-130 ms step in ~40 % of
+    # 20-30-step runs (tools/spike_hunt.py).  Collect now and freeze what is alive, as a training loop does after its first
+    # steps (engine.train_one_epoch); nothing of the step's GPU work is skipped.
+    U.quiesce_host_gc()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one event record per step: no synchronisation
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        loss, _ = step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    log(f"{tag}: per-step device time: min {per_step[0]:.2f}  median {per_step[len(per_step) // 2]:.2f}  max {per_step[-1]:.2f} ms")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    frames = batch * seq * world * steps
+    log(f"{tag}: timed {steps} steps in {dt:.3f} s")
+    res = {"value": frames / dt, "dt": dt, "ms_per_step": dt / steps * 1e3, "loss": float(loss),
+           "per_step": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)], "roofline": None}
+    gf = TRAIN_GFLOP_PER_FRAME.get((a.base_ch, skip, size))
+    if gf is not None:
+        res["model_tflops"] = round(res["value"] * gf / 1e3, 2)
+        res["model_mfma_frac"] = round(res["value"] * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+
+    if roofline:
+        # One instrumented step with every kernel on the launch stream: with the weight-gradient GEMMs overlapping on
+        # their side stream the events around a forward GEMM would also count the time it shares the CUs with them.
+        # EVERY rank runs it (the step contains the gradient all-reduce); only rank 0 records events.
+        async_was, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+        ops.PROFILE = [] if rank == 0 else None
+        ops.PROFILE_HBM = [] if rank == 0 else None
+        step()
+        torch.cuda.synchronize()
+        ops.ASYNC_WGRAD = async_was
+    if roofline and rank == 0:
+        agg = {}
+        rows = []
+        for kind, flops, e0, e1, note, nbytes in ops.PROFILE:
+            t_ms = e0.elapsed_time(e1)
+            rows.append((t_ms, kind, flops, note))
+            k = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
+            k[0] += flops
+            k[1] += t_ms
+            k[2] += 1
+            k[3] += nbytes
+        ops.PROFILE = None
+        hbm = {}
+        for kind, nbytes, e0, e1, _ in (ops.PROFILE_HBM or []):
+            k = hbm.setdefault(kind, [0.0, 0.0, 0])
+            k[0] += nbytes
+            k[1] += e0.elapsed_time(e1)
+            k[2] += 1
+        ops.PROFILE_HBM = None
+        if a.dump_launches:
+            merged = {}
+            for t_ms, kind, flops, note in rows:
+                m = merged.setdefault((kind, note), [0.0, 0.0, 0])
+                m[0] += t_ms
+                m[1] += flops
+                m[2] += 1
+            for (kind, note), (t_ms, flops, n) in sorted(merged.items(), key=lambda kv: -kv[1][0]):
+                log(f"{kind:16s} x{n:3d} {t_ms:8.3f} ms {flops / t_ms / 1e9:7.1f} TF/s  {note}")
+        if agg:
+            dom = max(agg, key=lambda k: agg[k][1])
+            fl, ms, n, nb = agg[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+            # --pmc WRITE_SIZE in separate runs of this same command, gfx950 correction applied: tools/pmc_traffic.py)
+            traffic, pmc = None, {}
+            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+            if (a.base_ch, skip, size, seq, batch) == (64, True, 64, 20, 32) and os.path.exists(tpath):
+                try:
+                    pmc = json.load(open(tpath))["kernels"]
+                    traffic = pmc[dom]["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
+            alg = nb / n
+
+            def with_ratio(k, v):
+                out = {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2],
+                       "algorithmic_bytes": round(v[3] / v[2])}
+                t = pmc.get(k, {}).get("hbm_bytes_per_launch") if isinstance(pmc, dict) else None
+                if t:
+                    out["traffic"] = t
+                    out["traffic_ratio"] = round(t / (v[3] / v[2]), 2)
+                return out
+
+            res["roofline"] = {
+                "bound": "mfma", "kernel": dom, "kernel_note": "epilogue family[tile shape the library picked]; rocprofv3 names: "
+                "patch128x256 = igemm_fwd_kernel<epi, 2, nsrc>, pertap128x128 = <epi, 0, nsrc>, pertap64x256 = <epi, 1, nsrc>, "
+                "ring64 = igemm_fwd_c64_kernel (epi 0 store, 1 fused ConvLSTM cell, 2 split-K slabs); igemm_wgrad[p3_256x256] = "
+                "igemm_wgrad_p3_kernel, [p2_*] = igemm_wgrad_p2_kernel, [generic] = igemm_wgrad_kernel",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch", "traffic_source": TRAFFIC_NOTE if traffic is not None else None,
+                # every operand read once + the result written once, averaged over the family's launches: traffic well
+                # above it = re-reads that missed L2 / the Infinity Cache
+                "algorithmic_bytes": round(alg), "traffic_ratio": round(traffic / alg, 2) if traffic else None,
+                "launches": n, "timing": "HIP events, one serialised step (side stream off)",
+                "avg_launch_ms": round(ms / n, 4),
+                "all": {k: with_ratio(k, v) for k, v in agg.items()},
+                # the HBM-bound kernels of the same step against the 8 TB/s HBM roofline: ALGORITHMIC bytes (each tensor
+                # read or written once) / HIP-event time
+                "hbm_bound": {k: {"gbs": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
+                                  "ms": round(v[1], 3), "launches": v[2], "algorithmic_bytes": round(v[0] / v[2]),
+                                  **({"traffic": pmc[k]["hbm_bytes_per_launch"], "traffic_ratio": round(pmc[k]["hbm_bytes_per_launch"] / (v[0] / v[2]), 2)}
+                                     if isinstance(pmc, dict) and k in pmc and pmc[k].get("hbm_bytes_per_launch") else {})}
+                              for k, v in hbm.items()}}
+    if world > 1:
+        dist.barrier()
+    return res
+
+
 def main():
+    global torch
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(self_launch(a))             # nothing has touched the GPU yet in this process
+        raise SystemExit(self_launch(a))             # this process has not even imported torch
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.scaling == "strong":
+        if a.global_batch % world:
+            raise SystemExit(f"--scaling strong: --global-batch {a.global_batch} is not a multiple of {world} ranks")
+        a.batch = a.global_batch // world
+    import torch as _torch
+    torch = _torch
     if a.dry_launch:
         return dry_launch(a, world, rank)
     if not torch.cuda.is_available():
@@ -235,142 +409,61 @@ def main():
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
     opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0, loss_scale=2.0 ** 14 if a.dtype == "f16" else None)
     ddp = U.FlatDDP(model, opt.flat, grad_dtype=torch.bfloat16 if a.bf16_buckets else None) if (world > 1 or a.force_ddp) else None
-    data = U.SyntheticSequences(a.batch, a.seq, a.size, a.size, seed=1 + rank, kind="uniform", device=dev)
-    x, y = data.x, data.y
-
-    def step():
-        return U.train_step(model, opt, x, y, None, False, ddp)      # USE_MASK = False, main.py:219
-
+    exchange = None
+    if ddp is not None:
+        exchange = ddp.describe()
+        # every rank says once what it is part of (stderr): the first N > 1 run should be readable from its log alone
+        print(f"[bench rank {rank}/{world}] device {torch.cuda.get_device_name(dev)} cuda:{local}, backend {dist.get_backend()}, "
+              f"world_size {dist.get_world_size()}, per-GPU batch {a.batch} ({a.scaling} scaling), {exchange['buckets']} buckets, "
+              f"{exchange['allreduce_bytes']} all-reduce bytes per step ({exchange['dtype']})", file=sys.stderr, flush=True)
     log(f"model + data ready ({sum(p.numel() for p in model.parameters())} parameters); warm-up x{a.warmup}")
-    for i in range(a.warmup):
-        step()
-        torch.cuda.synchronize()
-        log(f"warm-up step {i} done")
-    torch.cuda.synchronize()
-    # The timed region starts from a synchronised host: a generation-2 garbage collection (~75 ms of host time in a process
-    # that has imported torch) in its first steps is not hidden by run-ahead and showed up as ONE 60-130 ms step in ~40 % of
-    # 20-30-step runs (tools/spike_hunt.py).  Collect now and freeze what is alive, as a training loop does after its first
-    # steps (engine.train_one_epoch); nothing of the step's GPU work is skipped.
-    U.quiesce_host_gc()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # one event record per step: no synchronisation
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(a.steps):
-        loss, _ = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
-    log(f"per-step device time: min {per_step[0]:.2f}  median {per_step[len(per_step) // 2]:.2f}  max {per_step[-1]:.2f} ms")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    frames = a.batch * a.seq * world * a.steps
-    value = frames / dt
-    log(f"timed {a.steps} steps in {dt:.3f} s")
-    lossv = float(loss)
+
+    head = run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, size=a.size, seq=a.seq, batch=a.batch, steps=a.steps,
+                        warmup=a.warmup, roofline=not a.no_roofline, tag="headline")
     # does the weight-gradient stream still run beside the main stream?  (the runtime maps streams to hardware queues; two on one
     # queue serialise, which costs this step ~2.5 ms: recorded so that a slow run can be told from a slow box)
     side = ops.side_stream(dev)
     overlap = {"probes": ops._SIDE_STREAM_PROBES.get(str(dev)), "still_concurrent": bool(ops._streams_overlap(torch.cuda.current_stream(dev), side))}
 
-    roof = None
-    if not a.no_roofline:
-        # One instrumented step with every kernel on the launch stream: with the weight-gradient GEMMs overlapping on
-        # their side stream the events around a forward GEMM would also count the time it shares the CUs with them.
-        # EVERY rank runs it (the step contains the gradient all-reduce); only rank 0 records events.
-        async_was, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
-        ops.PROFILE = [] if rank == 0 else None
-        ops.PROFILE_HBM = [] if rank == 0 else None
-        step()
-        torch.cuda.synchronize()
-        ops.ASYNC_WGRAD = async_was
-    if not a.no_roofline and rank == 0:
-        agg = {}
-        rows = []
-        for kind, flops, e0, e1, note in ops.PROFILE:
-            t_ms = e0.elapsed_time(e1)
-            rows.append((t_ms, kind, flops, note))
-            k = agg.setdefault(kind, [0.0, 0.0, 0])
-            k[0] += flops
-            k[1] += t_ms
-            k[2] += 1
-        ops.PROFILE = None
-        hbm = {}
-        for kind, nbytes, e0, e1, _ in (ops.PROFILE_HBM or []):
-            k = hbm.setdefault(kind, [0.0, 0.0, 0])
-            k[0] += nbytes
-            k[1] += e0.elapsed_time(e1)
-            k[2] += 1
-        ops.PROFILE_HBM = None
-        if a.dump_launches:
-            merged = {}
-            for t_ms, kind, flops, note in rows:
-                m = merged.setdefault((kind, note), [0.0, 0.0, 0])
-                m[0] += t_ms
-                m[1] += flops
-                m[2] += 1
-            for (kind, note), (t_ms, flops, n) in sorted(merged.items(), key=lambda kv: -kv[1][0]):
-                log(f"{kind:16s} x{n:3d} {t_ms:8.3f} ms {flops / t_ms / 1e9:7.1f} TF/s  {note}")
-        if agg:
-            dom = max(agg, key=lambda k: agg[k][1])
-            fl, ms, n = agg[dom]
-            ach = fl / (ms * 1e-3) / 1e12
-            # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-            # --pmc WRITE_SIZE in separate runs of this same command, gfx950 correction applied: tools/pmc_traffic.py)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-            if (a.base_ch, skip, a.size, a.seq, a.batch) == (64, True, 64, 20, 32) and os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath))["kernels"][dom]["hbm_bytes_per_launch"]
-                except Exception:
-                    traffic = None
-            roof = {"bound": "mfma", "kernel": dom, "kernel_note": "epilogue family[tile shape the library picked]; rocprofv3 names: "
-                    "patch128x256 = igemm_fwd_kernel<epi, 2, nsrc>, pertap128x128 = <epi, 0, nsrc>, pertap64x256 = <epi, 1, nsrc>, "
-                    "ring64 = igemm_fwd_c64_kernel (epi 0 store, 1 fused ConvLSTM cell, 2 split-K slabs); igemm_wgrad[p3_256x256] = "
-                    "igemm_wgrad_p3_kernel, [p2_*] = igemm_wgrad_p2_kernel, [generic] = igemm_wgrad_kernel",
-                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch", "traffic_source": TRAFFIC_NOTE if traffic is not None else None,
-                    "launches": n, "timing": "HIP events, one serialised step (side stream off)",
-                    "avg_launch_ms": round(ms / n, 4),
-                    "all": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
-                            for k, v in agg.items()},
-                    # the HBM-bound kernels of the same step against the 8 TB/s HBM roofline: ALGORITHMIC bytes (each tensor
-                    # read or written once) / HIP-event time
-                    "hbm_bound": {k: {"gbs": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
-                                      "ms": round(v[1], 3), "launches": v[2]} for k, v in hbm.items()}}
-    if world > 1:
-        dist.barrier()
+    # The second north_star workload (cloud sequences 128x128 seq-8, preprocessing/build_sequences.py:15,108-131) on the same
+    # model, optimiser and ranks, right after the headline: 5 warm-up + 10 timed steps (~1.5 s of GPU time at N = 1).
+    second = None
+    if not a.no_secondary and (a.size, a.seq) == (64, 20) and a.mode == "train":
+        try:
+            r2 = run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, size=128, seq=8, batch=a.batch, steps=10, warmup=5,
+                              roofline=not a.no_roofline, tag="secondary")
+            second = {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) train step, 128x128 seq-8 (cloud "
+                                  f"sequences), per-GPU batch {a.batch}, AdamW+clip", "metric": "training frames/sec, cloud 128x128 seq-8",
+                      "value": round(r2["value"], 2), "unit": "frames/s", "steps": 10, "warmup": 5, "ms_per_step": round(r2["ms_per_step"], 3),
+                      "model_tflops": r2.get("model_tflops"), "model_mfma_frac": r2.get("model_mfma_frac"),
+                      "final_loss": round(r2["loss"], 5), "roofline": r2["roofline"]}
+        except Exception as e:          # the headline line must survive a failure here (same exception on every rank: no collective is left half-way)
+            second = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        gf = TRAIN_GFLOP_PER_FRAME.get((a.base_ch, skip, a.size))
         out = {
             "metric": ("training frames/sec, Moving-MNIST 64x64 seq-20" if (a.size, a.seq) == (64, 20)
                        else f"training frames/sec, {a.size}x{a.size} seq-{a.seq}"),
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(head["value"], 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(head["ms_per_step"], 3), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"TemporalUNetDualView(base_ch={a.base_ch}, use_skip_lstm={skip}) train step, "
                                    f"{a.size}x{a.size} seq-{a.seq}, per-GPU batch {a.batch}, AdamW+clip",
                        "global_batch": a.batch * world, "seq_len": a.seq, "parallelism": f"dp{world}"},
+            # 1 = no process group was created (single process, no gradient exchange)
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            **({"allreduce_bytes": exchange["allreduce_bytes"], "buckets": exchange["buckets"], "bucket_dtype": exchange["dtype"]} if exchange else {}),
             **({"rehearsal": "all ranks on cuda:0, collectives over gloo -- not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
-            "final_loss": round(lossv, 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
-            "step_ms_min_median_max": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)],
+            "final_loss": round(head["loss"], 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
+            "step_ms_min_median_max": head["per_step"],
         }
-        if gf is not None:
-            out["model_tflops"] = round(value * gf / 1e3, 2)
-            out["model_mfma_frac"] = round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
-        if roof is not None:
-            out["roofline"] = roof
+        for k in ("model_tflops", "model_mfma_frac"):
+            if k in head:
+                out[k] = head[k]
+        if head["roofline"] is not None:
+            out["roofline"] = head["roofline"]
+        if second is not None:
+            out["secondary"] = second
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size, a.seq)
         print(json.dumps(out), flush=True)

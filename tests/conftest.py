@@ -33,6 +33,70 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def mr_rel_l2_per_t(got, ref):
+    """Per-timestep rel-L2 of MEAN-REMOVED frames ([B,T,C,H,W]: the per-frame spatial mean is subtracted from both sides).
+    At random init the eval-mode output of the model is a DC offset (the outc bias) 60-230x larger than the spatial signal;
+    the raw rel-L2 is blind to a wrong signal there, this one is an error relative to the signal."""
+    g = got.double() - got.double().mean(dim=(-2, -1), keepdim=True)
+    r = ref.double() - ref.double().mean(dim=(-2, -1), keepdim=True)
+    return [float((g[:, t] - r[:, t]).norm() / (r[:, t].norm() + 1e-30)) for t in range(ref.shape[1])]
+
+
+EVAL_MR_CAP = 5e-2          # stated: eval-mode error <= 5 % of the spatial signal wherever the reference's own anchor is looser
+
+
+def eval_parity(name, model, g, sd, forward, pre="ac_", raw_tol=1e-2, cap=EVAL_MR_CAP):
+    """Eval-mode forward of ``model`` (``forward()`` -> [B,T,1,H,W] CPU tensor) against a seeded reference fixture, at random
+    init and with the reference's warmed running statistics loaded: raw per-timestep rel-L2 <= raw_tol and mean-removed
+    <= min(1.25 x the reference's own autocast eval drift (``pre``: ac_ = bf16, ac16_ = fp16), cap).  Restores ``sd``."""
+    worst = 0.0
+    for variant in ("", "_warm"):
+        if variant == "_warm":
+            model.load_state_dict({**sd, **{k[len("warm/"):]: v for k, v in g.items() if k.startswith("warm/")}})
+        got, ref = forward(), g["out_eval" + variant]
+        e_raw = [rel_l2(got[:, t], ref[:, t]) for t in range(ref.shape[1])]
+        e_mr = mr_rel_l2_per_t(got, ref)
+        anchor = [float(v) for v in g[pre + "eval_mr_rel_l2_per_t" + variant]]
+        print(f"[parity] {name}{variant}: eval forward vs reference per-timestep rel-L2 raw {[round(e, 6) for e in e_raw]} (tol {raw_tol}), "
+              f"mean-removed {[round(e, 5) for e in e_mr]}; the reference's own {pre}autocast eval drift, mean-removed "
+              f"{[round(e, 5) for e in anchor]} (bound min(1.25 x, {cap}))")
+        assert max(e_raw) <= raw_tol, f"{name}{variant}: raw eval rel-L2 {max(e_raw):.3e} > {raw_tol}"
+        for t, (e, r) in enumerate(zip(e_mr, anchor)):
+            assert e <= min(1.25 * r, cap), f"{name}{variant} t={t}: eval drift {e:.4f} of the signal > min(1.25 x {r:.4f}, {cap})"
+        worst = max(worst, max(e_mr))
+    model.load_state_dict(sd)
+    return worst
+
+
+def per_tensor_grad_report(names, got, want, ref_norms, anchor_rel, floor=2e-2, tiny=1e-6, cap=None):
+    """Per-parameter gradient parity: rel-L2(got_i, want_i) <= max(1.25 x anchor_rel[i], floor) and the norm within the same
+    band of the reference's own; tensors whose reference gradient is analytically zero (conv bias in front of BatchNorm:
+    the reference holds ~1e-9 noise there) must be ~zero instead.  Returns (failures, rows sorted by slack)."""
+    total = float(np.sqrt(sum(float(n) ** 2 for n in ref_norms)))
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        g, w = got[k].double().flatten(), want[k].double().flatten()
+        rn = float(ref_norms[i])
+        if rn <= tiny * total:
+            gn = float(g.norm())
+            rows.append((0.0, k, gn, rn, 0.0, "zero"))
+            if gn > 10 * tiny * total:
+                bad.append(f"{k}: reference gradient is ~0 ({rn:.2e}) but got norm {gn:.2e}")
+            continue
+        rel = float((g - w).norm() / (w.norm() + 1e-30))
+        bound = max(1.25 * float(anchor_rel[i]), floor)
+        if cap is not None:
+            bound = min(bound, cap)
+        dn = abs(float(g.norm()) - rn) / rn
+        rows.append((rel / bound, k, rel, bound, dn, ""))
+        if rel > bound:
+            bad.append(f"{k}: rel-L2 {rel:.4f} > {bound:.4f} (1.25 x reference autocast {float(anchor_rel[i]):.4f})")
+        if dn > bound:
+            bad.append(f"{k}: norm off by {dn:.4f} > {bound:.4f}")
+    rows.sort(reverse=True)
+    return bad, rows
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

@@ -258,6 +258,17 @@ def seeded_inputs(kind, B, T, H, W, seed):
     return d.x, d.y, d.mask
 
 
+def rel_per_t(got, ref):
+    return [float((got[:, t] - ref[:, t]).double().norm() / ref[:, t].double().norm()) for t in range(ref.shape[1])]
+
+
+def mr_rel_per_t(got, ref):
+    """Per-timestep rel-L2 of the MEAN-REMOVED frames (tests/conftest.py: mr_rel_l2_per_t is the same function)."""
+    g = got.double() - got.double().mean(dim=(-2, -1), keepdim=True)
+    r = ref.double() - ref.double().mean(dim=(-2, -1), keepdim=True)
+    return [float((g[:, t] - r[:, t]).norm() / r[:, t].norm()) for t in range(ref.shape[1])]
+
+
 def grad_stats(model):
     names = [k for k, _ in model.named_parameters()]
     return names, np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()], dtype=np.float64)
@@ -275,11 +286,39 @@ def gen_seeded(tag, *, base_ch, skip, B, T, HW, kind, seed, use_mask, lstm_layer
     arr = {"cfg": np.array([base_ch, int(skip), B, T, HW, seed, int(use_mask), lstm_layers], dtype=np.int64),
            "kind": np.array(kind), "param_checksum": checksum(model.parameters()), "input_checksum": checksum([x, y, mask])}
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.eval()
+
+    def eval_block(suffix):
+        """Eval-mode forward in f32 plus the REFERENCE's own drift under autocast on the same weights, as raw per-timestep
+        rel-L2 and MEAN-REMOVED (per-frame spatial mean subtracted from both sides: at random init the eval output is a DC
+        offset -- the outc bias -- 60-230x larger than the spatial signal, so the raw figure cannot see a wrong signal)."""
+        model.eval()
+        with torch.no_grad():
+            outs, _ = model(x)
+            ref = torch.stack(outs, dim=1)
+            arr["out_eval" + suffix] = npy(ref)
+            sig = float((ref - ref.mean(dim=(-2, -1), keepdim=True)).std())
+            print(f"{tag}{suffix}: eval |out| mean {float(ref.abs().mean()):.4f}, spatial signal std {sig:.5f}")
+            for pre, adt in (("ac_", torch.bfloat16),) + ((("ac16_", torch.float16),) if with_fp16 else ()):
+                with torch.autocast("cpu", dtype=adt):
+                    o2, _ = model(x)
+                got = torch.stack([o.float() for o in o2], dim=1)
+                arr[pre + "eval_rel_l2_per_t" + suffix] = np.array(rel_per_t(got, ref), dtype=np.float64)
+                arr[pre + "eval_mr_rel_l2_per_t" + suffix] = np.array(mr_rel_per_t(got, ref), dtype=np.float64)
+                print(f"{tag}{suffix}: reference {pre}autocast EVAL drift per-t raw {[round(e, 6) for e in arr[pre + 'eval_rel_l2_per_t' + suffix]]} "
+                      f"mean-removed {[round(e, 5) for e in arr[pre + 'eval_mr_rel_l2_per_t' + suffix]]}")
+
+    eval_block("")
+    # a second eval case with NON-TRIVIAL running statistics: three train-mode forwards first (3 x T momentum updates per
+    # BatchNorm, train/unet.py:179,:196), their buffers stored (small: per-channel vectors) so that a test can load them
+    model.train()
     with torch.no_grad():
-        outs, _ = model(x)
-        arr["out_eval"] = np.stack([npy(o) for o in outs], axis=1)
-        print(f"{tag}: eval |out| mean {float(np.abs(arr['out_eval']).mean()):.4f}")
+        for _ in range(3):
+            model(x)
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            arr["warm/" + k] = npy(v)
+    eval_block("_warm")
+    model.load_state_dict(sd0)
     if with_step:
         model.train()
         model.zero_grad(set_to_none=True)
@@ -334,6 +373,7 @@ def gen_seeded(tag, *, base_ch, skip, B, T, HW, kind, seed, use_mask, lstm_layer
                 g = p_.grad.detach().double()
                 pt.append(float((g - r).norm() / (r.norm() + 1e-30)))
             arr["ac_grad_rel_l2_per_tensor"] = np.array(pt, dtype=np.float64)
+            arr["ac_grad_norms"] = np.array([float(p_.grad.double().norm()) for _, p_ in model.named_parameters()], dtype=np.float64)
             err_t = [float((y_ac[:, t] - y_pred[:, t]).double().norm() / y_pred[:, t].double().norm()) for t in range(T)]
             arr["ac_out_rel_l2_per_t"] = np.array(err_t, dtype=np.float64)
             print(f"{tag}: reference autocast drift: out per-t {[round(e, 5) for e in err_t]}, loss {float(loss_ac):.6f} vs "
@@ -415,10 +455,11 @@ SEEDED = {
     "ref_cloud128": dict(base_ch=16, skip=True, B=4, T=3, HW=128, kind="blobs", seed=930, use_mask=True),
     # configs[3]: 256x256
     "ref_256": dict(base_ch=8, skip=True, B=2, T=2, HW=256, kind="uniform", seed=940, use_mask=False, with_fp16=True),
-    # configs[4]: 512x512 rollout (inference only)
-    # (seed 950 draws an output head whose terms cancel: |out| = 0.004 against activations of 0.3, so the same absolute error
-    #  as every other case -- 4e-5 -- reads as rel-L2 1.05e-2 there; 952 is the next seed whose |out| is of the activations' order)
+    # configs[4]: 512x512 rollout (inference only).  Two seeds: 950 draws a small output bias (|out| = 0.004), so its RAW
+    # rel-L2 reads the signal-relative error (1.05e-2 on the HIP path in round 2); 952 draws a DC offset of 0.3.  Both are
+    # judged on the mean-removed metric against the reference's own autocast eval drift.
     "ref_512": dict(base_ch=8, skip=True, B=1, T=3, HW=512, kind="uniform", seed=952, use_mask=False, with_step=False),
+    "ref_512_s950": dict(base_ch=8, skip=True, B=1, T=3, HW=512, kind="uniform", seed=950, use_mask=False, with_step=False),
 }
 
 

@@ -380,7 +380,7 @@ def test_flat_ddp_counts_uses_of_side_written_gradients():
         ddp._on_ready(ib)                                  # autograd's accumulator: once per backward, completes at once
         assert sorted(launched) == list(range(len(ddp.buckets)))
         ddp.finalize()
-        with pytest.raises(AssertionError):
+        with pytest.raises(RuntimeError, match="announced 3 gradients for 2 recorded uses"):
             U.ops.grad_written(w)                          # a third announcement for two uses is a protocol error
         # gradient accumulation: passes inside no_sync() are invisible
         launched.clear()
@@ -395,8 +395,41 @@ def test_flat_ddp_counts_uses_of_side_written_gradients():
         ddp._on_ready(ib)
         assert sorted(launched) == list(range(len(ddp.buckets)))
         ddp.finalize()
+        # a forward inside no_sync() whose backward runs outside (or a forward before reset()): the number of uses of this
+        # pass is unknown, so a side announcement must NOT release the bucket on the first of T per-timestep gradients --
+        # it is left to finalize() (uses 0 -> expected max(1, 0) = 1 released early, then asserted)
+        launched.clear()
+        ddp.reset()
+        with ddp.no_sync():
+            U.ops.note_use(w)
+            U.ops.note_use(w)
+        U.ops.grad_written(w)
+        U.ops.grad_written(w)
+        assert not launched and not ddp._done[iw]
+        ddp.reset()
+        U.ops.grad_written(w)                              # gradient of a forward that ran before reset(): never early
+        assert not launched and not ddp._done[iw]
+        ddp.finalize()
+        assert sorted(launched) == list(range(len(ddp.buckets)))
+        # one gradient buffer, one wrapper
+        with pytest.raises(RuntimeError, match="already belong"):
+            FlatDDP(net, fp)
         ddp.remove_hooks()
         assert not U.ops.USE_HOOKS and not U.ops.GRAD_SIDE_HOOKS
+        # a wrapper dropped WITHOUT remove_hooks() takes its global hooks with it
+        d2 = FlatDDP(net, fp)
+        assert len(U.ops.USE_HOOKS) == 1 and len(U.ops.GRAD_SIDE_HOOKS) == 1
+        for h in d2._hooks:
+            h.remove()
+        d2._hooks = []
+        del d2
+        import gc
+        gc.collect()
+        assert not U.ops.USE_HOOKS and not U.ops.GRAD_SIDE_HOOKS
+        d3 = FlatDDP(net, fp)
+        assert d3.describe() == {"buckets": len(d3.buckets), "allreduce_bytes": 4 * fp.numel, "dtype": "f32", "world_size": 1,
+                                 "bucket_bytes": [4 * (hi - lo) for lo, hi in d3.ranges]}
+        d3.remove_hooks()
     finally:
         dist.destroy_process_group()
 
@@ -416,6 +449,23 @@ def test_bench_self_launch_starts_n_ranks():
     out = json.loads(line)
     assert out["dry_launch"] and out["n_gpus"] == 2
     assert sorted(x["rank"] for x in out["ranks"]) == [0, 1] and all(x["world_size"] == 2 for x in out["ranks"])
+    assert out["scaling"] == "weak" and all(x["per_gpu_batch"] == 32 for x in out["ranks"]) and out["global_batch"] == 64
+    # strong scaling: the global batch is fixed and divided over the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--scaling", "strong", "--global-batch", "32"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["global_batch"] == 32 and all(x["per_gpu_batch"] == 16 for x in out["ranks"])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--scaling", "strong", "--global-batch", "33"],
+                       env={**env, "RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"}, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "multiple" in (r.stderr + r.stdout)
+    # the launcher parent never loads torch (a process that starts GPU programs makes no GPU call, not even a device count)
+    probe = ("import sys, runpy; sys.argv=['bench.py','--gpus','2','--dry-launch'];\n"
+             "import subprocess; subprocess.run=lambda *a, **k: type('R', (), {'returncode': 0})()\n"
+             "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit: pass\n"
+             "print('TORCH_LOADED' if 'torch' in sys.modules else 'TORCH_ABSENT')" % os.path.join(root, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
+    assert "TORCH_ABSENT" in r.stdout, (r.stdout, r.stderr[-1000:])
     # a rank count that does not match --gpus is refused, never silently run as one rank
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"],
                        env={**env, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, capture_output=True, text=True, timeout=120)

@@ -5,7 +5,13 @@ loss and per-tensor gradient norms, plus the reference's OWN drift when it runs 
 mode.  Weights and inputs are re-created from the recorded seeds and verified against recorded checksums.
 
 Stated tolerances (bf16 kernels vs the fp32 reference):
-  eval-mode forward      per-timestep rel-L2 <= 1e-2
+  eval-mode forward      per-timestep rel-L2 <= 1e-2 on the raw output (weak: at random init the output is a DC offset 60-230x
+                         the spatial signal) AND, on MEAN-REMOVED frames (error relative to the signal),
+                         <= min(1.25 x the reference's own bf16-autocast eval drift on the same case, EVAL_MR_CAP);
+                         twice: at random init and with running statistics populated by three reference train-mode forwards
+                         (the fixture holds those buffers).  The cap matters where the reference's autocast anchor is
+                         useless: its bf16 OUTPUT rounds a 0.3 offset to 1e-3, i.e. away the whole 2e-3 signal (drift 0.31),
+                         while this path writes the output layer in f32.
   train-mode forward     per-timestep rel-L2 <= 1.25 x the reference's own bf16-autocast drift on the same case
                          (2.2e-2 at base_ch 64 / B 32, 2.6e-2 at base_ch 8 / B 16: batch-statistics BatchNorm at random
                          init re-amplifies every bf16 rounding; the reference does it too)
@@ -18,7 +24,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import seeded_case, load_golden_np, checksum, rel_l2
+from conftest import seeded_case, load_golden_np, checksum, rel_l2, mr_rel_l2_per_t, per_tensor_grad_report, eval_parity, EVAL_MR_CAP
 
 pytestmark = pytest.mark.gpu
 
@@ -57,11 +63,12 @@ def check_case(name, expect_kernels=(), check_grads=True):
     g, sd, x, y, mask, cfg = seeded_case(name)
     model = build(sd, cfg).eval()
     xd, yd, md = x.to(DEV), y.to(DEV), mask.to(DEV)
-    with torch.no_grad():
-        outs, _ = model(xd)
-    e_eval = per_t(torch.stack(outs, 1).cpu(), g["out_eval"])
-    print(f"[parity] {name}: eval forward vs reference per-timestep rel-L2 {[round(e, 6) for e in e_eval]} (tol 1e-2)")
-    assert max(e_eval) <= 1e-2
+    def forward():
+        with torch.no_grad():
+            outs, _ = model(xd)
+        return torch.stack(outs, 1).cpu()
+
+    eval_parity(name, model, g, sd, forward)
     if "out_train" not in g:
         return g, model, xd
     model.train()
@@ -98,6 +105,16 @@ def check_case(name, expect_kernels=(), check_grads=True):
         print(f"[parity] {name}: whole gradient vs f32 oracle rel-L2 {r:.4f} cosine {c:.5f}; the reference's own autocast "
               f"gradient drift rel-L2 {r_ref:.4f} cosine {c_ref:.5f}")
         assert r <= 1.25 * r_ref and (1 - c) <= 1.25 * (1 - c_ref)
+        # every parameter tensor on its own (the whole-vector figure is dominated by the three ConvLSTM weights and cannot
+        # see a wrong outc / BatchNorm gamma, beta / bias gradient): HIP vs f32 oracle against the reference's OWN per-tensor
+        # autocast drift, and the norm against the reference's per-tensor norm
+        names = [k for k, _ in model.named_parameters()]
+        assert names == [str(n) for n in g["grad_names"]]
+        bad, rows = per_tensor_grad_report(names, {k: p.grad.cpu() for k, p in model.named_parameters()}, rg,
+                                           [float(v) for v in g["grad_norms"]], [float(v) for v in g["ac_grad_rel_l2_per_tensor"]])
+        print(f"[parity] {name}: per-tensor gradients, worst five of {len(rows)} (rel-L2 / bound): " +
+              "; ".join(f"{k} {rel:.4f}/{bound:.4f}" for _, k, rel, bound, _, z in rows[:5] if not z))
+        assert not bad, f"{name}: " + " | ".join(bad[:8])
     return g, model, xd
 
 
@@ -138,20 +155,25 @@ def test_config3_256_vs_reference():
     check_case("ref_256")
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_config4_512_rollout_vs_reference(use_graph):
+@pytest.mark.parametrize("case,use_graph", [("ref_512", True), ("ref_512", False), ("ref_512_s950", True)])
+def test_config4_512_rollout_vs_reference(case, use_graph):
     """BASELINE configs[4]: 512x512, inference only.  Full-sequence eval forward vs the reference fixture, then the stateful
     frame-by-frame rollout (captured HIP graph) vs both."""
-    g, model, xd = check_case("ref_512")
+    g, model, xd = check_case(case)
     with torch.no_grad():
         full, _ = model(xd)
     full = torch.stack(full, 1).cpu()
     sp = U.StreamingPredictor(model, use_graph=use_graph, warmup=1)
     got = sp.rollout(xd).cpu()
     e_full, e_ref = per_t(got, full), per_t(got, g["out_eval"])
-    print(f"[parity] ref_512 rollout (graph={use_graph}): vs full-sequence forward {[round(e, 6) for e in e_full]}, vs reference "
-          f"{[round(e, 6) for e in e_ref]}")
-    assert max(e_full) <= 2e-3 and max(e_ref) <= 1e-2
+    m_full, m_ref = mr_rel_l2_per_t(got, full), mr_rel_l2_per_t(got, g["out_eval"])
+    anchor = [float(v) for v in g["ac_eval_mr_rel_l2_per_t"]]
+    print(f"[parity] {case} rollout (graph={use_graph}): vs full-sequence forward {[round(e, 6) for e in e_full]} (mean-removed "
+          f"{[round(e, 5) for e in m_full]}), vs reference {[round(e, 6) for e in e_ref]} (mean-removed {[round(e, 5) for e in m_ref]}, "
+          f"reference autocast {[round(e, 5) for e in anchor]})")
+    # seed 950's output is all signal (|out| 0.004): its raw figure IS the signal-relative one and sits at the reference's own 1.1e-2
+    assert max(e_full) <= 2e-3 and max(e_ref) <= (1.25 * 1.13e-2 if case.endswith("s950") else 1e-2)
+    assert max(m_full) <= 2e-2 and all(e <= min(1.25 * r, EVAL_MR_CAP) for e, r in zip(m_ref, anchor))
     if use_graph:
         assert all(g is not None for g in sp._graphs)
 
@@ -243,3 +265,122 @@ def test_config1_full_size_properties():
         e = max(per_t(roll.cpu(), full[:4].cpu()))
         print(f"[parity] full-size eval: 20-frame stateful rollout (HIP graph) vs full-sequence forward, worst rel-L2 {e:.2e}")
         assert e <= 5e-3            # measured 2.4e-3 (batch 4 frame by frame vs batch 32 in one pass: different kernel plans, as above)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[2], [3], [4] at their FULL size (base_ch 64 + skip LSTMs): too large for the CPU oracle, so size-independent
+# properties, with the kernel plan asserted through ops.LAUNCH_LOG -- the strip-mode patch tiles on the C >= 128 levels of
+# images wider than 64 pixels, the 256 x 256 / 8-phase weight gradient, the ring kernels, and the launch splitting at the
+# 2-GiB descriptor range run HERE and nowhere else in the suite at real sizes.
+# ---------------------------------------------------------------------------------------------
+def _full_size_properties(size, T, B, dtype, indep=(0,), roll_b=2, train_tol=1e-6, seed=31):
+    """(a) a training step run twice from the same state gives the same loss and, to f32 rounding, the same gradient (no float
+    atomics); (b) eval-mode batch independence: sample b inside the batch == that sample alone (different kernel plans);
+    (c) the stateful frame-by-frame rollout (HIP graph) == the full-sequence forward.  Returns the launch log of (a)."""
+    torch.manual_seed(seed)
+    with ops.compute_dtype(dtype):
+        model = U.TemporalUNetDualView(1, 1, base_ch=64, use_skip_lstm=True).to(DEV)
+        data = U.SyntheticSequences(B, T, size, size, seed=seed + 1, kind="uniform")
+        opt = U.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_grad_norm=None,
+                           loss_scale=2.0 ** 14 if dtype == torch.float16 else None)
+        model.train()
+        runs, log = [], None
+        for i in range(2):
+            ops.LAUNCH_LOG = [] if i == 0 else None
+            loss, _ = U.train_step(model, opt, data.x, data.y, data.mask, True, clip_norm=None)
+            if i == 0:
+                log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+            runs.append((float(loss), opt.flat.flat_g.detach().clone()))
+        d = rel_l2(runs[1][1].cpu(), runs[0][1].cpu())
+        print(f"[parity] {size}x{size} T={T} B={B} {dtype}: step twice: loss {runs[0][0]:.6f} / {runs[1][0]:.6f}, gradient rel-L2 {d:.2e}")
+        assert runs[0][0] == runs[1][0] and d <= train_tol and bool(torch.isfinite(runs[0][1]).all()) and float(runs[0][1].abs().max()) > 0
+        model.eval()
+        with torch.no_grad():
+            full, _ = model(data.x)
+            full = torch.stack(full, 1)
+            for b in indep:
+                one, _ = model(data.x[b:b + 1].contiguous())
+                e = max(per_t(torch.stack(one, 1).cpu(), full[b:b + 1].cpu()))
+                m = max(mr_rel_l2_per_t(torch.stack(one, 1).cpu(), full[b:b + 1].cpu()))
+                print(f"[parity] {size}x{size} eval: sample {b} alone vs inside the B={B} batch, worst per-timestep rel-L2 {e:.2e} (mean-removed {m:.2e})")
+                assert e <= 5e-3 and m <= EVAL_MR_CAP
+            sp = U.StreamingPredictor(model, use_graph=True, warmup=1)
+            roll = sp.rollout(data.x[:roll_b].contiguous())
+            e = max(per_t(roll.cpu(), full[:roll_b].cpu()))
+            m = max(mr_rel_l2_per_t(roll.cpu(), full[:roll_b].cpu()))
+            print(f"[parity] {size}x{size} eval: {T}-frame stateful rollout (HIP graph) vs full-sequence forward, worst rel-L2 {e:.2e} (mean-removed {m:.2e})")
+            assert e <= 5e-3 and m <= EVAL_MR_CAP
+    return log
+
+
+def _fwd(log, epi, shape, min_width=0):
+    return [r for r in log if r[0] == "fwd" and r[1] == epi and r[2] == shape and r[3] >= min_width]
+
+
+def test_config2_full_size_properties():
+    """BASELINE configs[2]: cloud 128x128 seq-8, per-GPU batch 32, base_ch 64 + skip LSTMs."""
+    log = _full_size_properties(128, 8, 32, torch.bfloat16, indep=(0, 31), roll_b=4)
+    assert _fwd(log, 0, 2) and _fwd(log, 0, 3, 128), "patch loop / ring kernel on 128-wide images not exercised"
+    assert _fwd(log, 1, 2) or _fwd(log, 2, 2), "ConvLSTM recurrence kernels not exercised"
+    assert any(r[0] == "wgrad" and r[1] == 3 for r in log) and any(r[0] == "wgrad" and r[1] == 4 for r in log), "p3 / ring weight gradients"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config3_full_size_properties(dtype):
+    """BASELINE configs[3]: 256x256 seq-12, per-GPU batch 4, 4-level UNet-ConvLSTM at base_ch 64, bf16 and the fp16-MFMA twins.
+    The 128x128 level has C = 128: the strip-mode patch tiles (4-row x 64-column blocks of one image) run here."""
+    log = _full_size_properties(256, 12, 4, dtype, indep=(0, 3), roll_b=2, train_tol=1e-6 if dtype == torch.bfloat16 else 1e-5)
+    assert _fwd(log, 0, 2, 128), f"strip-mode patch loop (images wider than 64 pixels, C_out >= 128) not exercised: {sorted(set(log))[:12]}"
+    assert any(r[0] == "wgrad" and r[1] == 3 for r in log), "256 x 256 / 8-phase weight gradient not exercised"
+
+
+def test_config3_reference_batch_is_cut_at_the_descriptor_range():
+    """The reference's own 256x256 setting (main.py: B = 32, T = 8): 2^31 bytes in the full-resolution activations, so the
+    inc / up0 launches are cut into image ranges on BatchNorm-group boundaries (ops._img_chunks).  Reproducible training step,
+    finite gradients, and eval-mode batch independence through the SPLIT launches."""
+    torch.manual_seed(41)
+    model = U.TemporalUNetDualView(1, 1, base_ch=64, use_skip_lstm=True).to(DEV)
+    data = U.SyntheticSequences(32, 8, 256, 256, seed=42, kind="uniform")
+    opt = U.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_grad_norm=None)
+    model.train()
+    runs = []
+    for i in range(2):
+        ops.LAUNCH_LOG = [] if i == 0 else None
+        loss, _ = U.train_step(model, opt, data.x, data.y, None, False, clip_norm=None)
+        if i == 0:
+            log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        runs.append((float(loss), opt.flat.flat_g.detach().clone()))
+    splits = [r for r in log if r[0] == "split"]
+    print(f"[parity] 256x256 B=32 T=8: split launches {sorted(set(splits))}; loss {runs[0][0]:.6f} / {runs[1][0]:.6f}")
+    assert any(r[1] == "igemm_fwd(store)" for r in splits) and any(r[1] == "igemm_wgrad" for r in splits)
+    assert runs[0][0] == runs[1][0] and rel_l2(runs[1][1].cpu(), runs[0][1].cpu()) <= 1e-6 and bool(torch.isfinite(runs[0][1]).all())
+    del runs, opt
+    model.eval()
+    with torch.no_grad():
+        full, _ = model(data.x)
+        one, _ = model(data.x[31:32].contiguous())
+        got, ref = torch.stack(one, 1).cpu(), torch.stack(full, 1)[31:32].cpu()
+    e, m = max(per_t(got, ref)), max(mr_rel_l2_per_t(got, ref))
+    print(f"[parity] 256x256 B=32 T=8 eval: sample 31 alone vs inside the split batch: rel-L2 {e:.2e} (mean-removed {m:.2e})")
+    assert e <= 5e-3 and m <= EVAL_MR_CAP
+
+
+def test_config4_full_size_properties():
+    """BASELINE configs[4]: 512x512 seq-20 autoregressive rollout, inference only, base_ch 64 + skip LSTMs, batch 1: the
+    hipGraph-captured recurrent step equals the full-sequence forward, and graph replay equals eager frame-by-frame."""
+    torch.manual_seed(51)
+    model = U.TemporalUNetDualView(1, 1, base_ch=64, use_skip_lstm=True).to(DEV).eval()
+    x = U.SyntheticSequences(1, 20, 512, 512, seed=52, kind="uniform").x
+    with torch.no_grad():
+        ops.LAUNCH_LOG = []
+        full, _ = model(x)
+        log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        full = torch.stack(full, 1).cpu()
+        a = U.StreamingPredictor(model, use_graph=True, warmup=1).rollout(x).cpu()
+        b = U.StreamingPredictor(model, use_graph=False).rollout(x).cpu()
+    assert _fwd(log, 0, 2, 128), "strip-mode patch loop not exercised by the 512x512 forward"
+    e, m = max(per_t(a, full)), max(mr_rel_l2_per_t(a, full))
+    print(f"[parity] 512x512 T=20 B=1: rollout (HIP graph) vs full-sequence forward rel-L2 {e:.2e} (mean-removed {m:.2e}); graph vs eager "
+          f"max |diff| {float((a - b).abs().max()):.1e}")
+    assert torch.equal(a, b), "graph replay differs from eager frame-by-frame"
+    assert e <= 5e-3 and m <= EVAL_MR_CAP and bool(torch.isfinite(a).all())

@@ -12,12 +12,21 @@ Backend-agnostic: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the CPU tests.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
 from .optim import FlatParams
+
+
+def _unregister(side_hook, use_hook) -> None:
+    from . import ops
+    if side_hook in ops.GRAD_SIDE_HOOKS:
+        ops.GRAD_SIDE_HOOKS.remove(side_hook)
+    if use_hook in ops.USE_HOOKS:
+        ops.USE_HOOKS.remove(use_hook)
 
 
 class FlatDDP:
@@ -29,6 +38,11 @@ class FlatDDP:
             raise RuntimeError("FlatDDP: torch.distributed is not initialised")
         if grad_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("FlatDDP: grad_dtype must be None / torch.float32 / torch.bfloat16")
+        owner = getattr(flat, "_ddp_owner", None)
+        if owner is not None and owner() is not None and owner()._hooks:
+            # two wrappers on one gradient buffer would each all-reduce every bucket: the gradients would be averaged twice
+            raise RuntimeError("FlatDDP: these FlatParams already belong to a live FlatDDP; call remove_hooks() on it first")
+        flat._ddp_owner = weakref.ref(self)
         self.module, self.flat, self.pg = module, flat, process_group
         self.grad_dtype = None if grad_dtype in (None, torch.float32) else grad_dtype
         self._stage = torch.empty_like(flat.flat_g, dtype=self.grad_dtype) if self.grad_dtype is not None else None
@@ -85,36 +99,77 @@ class FlatDDP:
         self._done = [False] * len(flat.params)
         self._sync = True
         from . import ops
-        self._side_hook = lambda param: self._on_ready(self._index_of[id(param)], True) if id(param) in self._index_of else None
-        self._use_hook = self._on_use
-        ops.GRAD_SIDE_HOOKS.append(self._side_hook)
-        ops.USE_HOOKS.append(self._use_hook)
+        # The operator layer keeps its hook lists in module globals: register through a weak reference, so that a wrapper
+        # that is dropped without remove_hooks() takes its hooks with it instead of all-reducing behind its successor.
+        me = weakref.ref(self)
+
+        def side_hook(param):
+            o = me()
+            if o is None:
+                _unregister(side_hook, use_hook)
+            elif id(param) in o._index_of:
+                o._on_ready(o._index_of[id(param)], True)
+
+        def use_hook(param):
+            o = me()
+            if o is None:
+                _unregister(side_hook, use_hook)
+            else:
+                o._on_use(param)
+
+        self._side_hook, self._use_hook = side_hook, use_hook
+        ops.GRAD_SIDE_HOOKS.append(side_hook)
+        ops.USE_HOOKS.append(use_hook)
+        weakref.finalize(self, _unregister, side_hook, use_hook)
         self._main_stream = None
         self.reset()
 
+    def describe(self) -> dict:
+        """What one step exchanges: bucket count, all-reduce bytes per step and the dtype on the wire."""
+        el = 2 if self.grad_dtype is not None else 4
+        return {"buckets": len(self.buckets), "allreduce_bytes": int(self.flat.numel) * el,
+                "dtype": "bf16" if self.grad_dtype is not None else "f32", "world_size": self.world,
+                "bucket_bytes": [int(hi - lo) * el for lo, hi in self.ranges]}
+
     def _on_use(self, param) -> None:
         i = self._index_of.get(id(param))
-        if i is not None and self._sync:
+        if i is None:
+            return
+        if self._sync:
             self._uses[i] += 1
+        else:
+            self._unsynced_uses[i] += 1
 
     def _on_ready(self, i: int, side: bool = False) -> None:
         """Gradient ``i`` has been produced.  ``side``: announced by an operator that wrote ``.grad`` itself -- once per USE
         of the parameter, so the parameter is complete only after as many announcements as forward reported uses;
         autograd's own accumulator (``side=False``) fires once per backward pass, after all uses."""
         if not self._sync:
+            if side and self._unsynced_uses[i] > 0:
+                self._unsynced_uses[i] -= 1          # a pass that ran entirely inside no_sync() pays its own uses off
             return
         if side:
+            if self._unsynced_uses[i]:
+                # some of this parameter's uses were recorded inside no_sync() (or a forward ran there and its backward runs
+                # here): the use count of THIS pass is unknown, so nothing is released early -- finalize() launches the bucket
+                return
+            if self._uses[i] == 0:
+                # a gradient for a parameter whose forward was never reported (forward before reset(), or by code that does
+                # not call ops.note_use): completeness cannot be told from announcements; leave it to finalize()
+                return
             self._seen[i] += 1
-            expected = max(1, self._uses[i])
-            assert self._seen[i] <= expected, f"FlatDDP: parameter {i} announced {self._seen[i]} gradients for {expected} uses"
-            if self._seen[i] < expected:
+            if self._seen[i] > self._uses[i]:
+                raise RuntimeError(f"FlatDDP: parameter {i} announced {self._seen[i]} gradients for {self._uses[i]} recorded uses "
+                                   "(call reset() before every forward pass; do not mix passes of different steps)")
+            if self._seen[i] < self._uses[i]:
                 return
         if self._done[i]:
             return
         self._done[i] = True
         bi = self.bucket_of[i]
         self._pending[bi] -= 1
-        assert self._pending[bi] >= 0, f"FlatDDP: bucket {bi} completed more gradients than it holds"
+        if self._pending[bi] < 0:
+            raise RuntimeError(f"FlatDDP: bucket {bi} completed more gradients than it holds (reset() missing before this step?)")
         if self._pending[bi] == 0:
             self._launch(bi)
 
@@ -172,6 +227,7 @@ class FlatDDP:
         self._pending = [len(b) for b in self.buckets]
         self._handles = [None] * len(self.buckets)
         self._uses = [0] * len(self.flat.params)
+        self._unsynced_uses = [0] * len(self.flat.params)
         self._seen = [0] * len(self.flat.params)
         self._done = [False] * len(self.flat.params)
         if self.flat.flat_g.is_cuda:
@@ -195,11 +251,7 @@ class FlatDDP:
             h.remove()
         self._hooks = []
         if getattr(self, "_side_hook", None) is not None:
-            from . import ops
-            if self._side_hook in ops.GRAD_SIDE_HOOKS:
-                ops.GRAD_SIDE_HOOKS.remove(self._side_hook)
-            if self._use_hook in ops.USE_HOOKS:
-                ops.USE_HOOKS.remove(self._use_hook)
+            _unregister(self._side_hook, self._use_hook)
             self._side_hook = self._use_hook = None
 
     def __call__(self, *a, **k):

@@ -96,13 +96,20 @@ SHAPE_LOG: Optional[list] = None
 KERNEL_LOG: Optional[list] = None
 
 
+# Same again with the geometry, for the full-size property tests: ("fwd", epilogue, shape, image width, N), ("wgrad", shape,
+# N, Ktot, pixel-range slabs) and ("split", what, image ranges) for a launch cut at the 2-GiB descriptor range.
+LAUNCH_LOG: Optional[list] = None
+
+
 def _log_shape(d) -> None:
-    if SHAPE_LOG is not None or KERNEL_LOG is not None:
+    if SHAPE_LOG is not None or KERNEL_LOG is not None or LAUNCH_LOG is not None:
         shp = int(L.lib.uclstm_igemm_fwd_shape(C.byref(d)))
         if SHAPE_LOG is not None:
             SHAPE_LOG.append(shp)
         if KERNEL_LOG is not None:
             KERNEL_LOG.append((int(d.epi), shp))
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.append(("fwd", int(d.epi), shp, int(d.W), int(d.N)))
 
 
 # Same for the HBM-bound kernels (BatchNorm passes, pooling, LSTM point-wise): (kernel, algorithmic BYTES, start, stop, note).
@@ -133,7 +140,9 @@ def _kernel_kind(kind: str, d) -> str:
     return f"{kind}[{_SHAPE_NAMES.get(int(L.lib.uclstm_igemm_fwd_shape(C.byref(d))), '?')}]"
 
 
-def _timed(kind: str, flops: float, launch, note: str = "") -> None:
+def _timed(kind: str, flops: float, launch, note: str = "", nbytes: float = 0.0) -> None:
+    """``nbytes``: ALGORITHMIC HBM bytes of the launch -- every operand read once, the result written once (split-K /
+    pixel-range slabs counted as ONE result) -- the partner of the PMC traffic figure in bench.py's roofline leg."""
     if PROFILE is None:
         launch()
         return
@@ -142,7 +151,11 @@ def _timed(kind: str, flops: float, launch, note: str = "") -> None:
     e0.record()
     launch()
     e1.record()
-    PROFILE.append((kind, flops, e0, e1, note))
+    PROFILE.append((kind, flops, e0, e1, note, float(nbytes)))
+
+
+def _nb(*tensors) -> int:
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -758,6 +771,8 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
     per_img = max([_bytes_per_img(sv.t) for sv in srcs] + [_bytes_per_img(sg[0]) for sg in segs])
     chunks = _img_chunks(n_img, groups, per_img, "igemm_fwd(store)", whole_groups=stats is not None)
     if len(chunks) > 1:
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.append(("split", "igemm_fwd(store)", len(chunks)))
         ipg = n_img // groups
         for i0, i1 in chunks:
             sub_src = [SrcView(sv.t[i0:i1], sv.offY, sv.offX) for sv in srcs]
@@ -800,7 +815,8 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
     _same_act_dtype([sv.t for sv in srcs] + [wp] + [sg[0] for sg in segs], "igemm_fwd(store)")
     K = _k(wp)
     _timed(_kernel_kind("igemm_fwd_store", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(store)"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}")
+           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} nsrc={len(srcs)} nseg={len(segs)}",
+           nbytes=_nb(*[sv.t for sv in srcs], wp) + 2.0 * n_img * out_hw[0] * out_hw[1] * d.N if PROFILE is not None else 0.0)
 
 
 def split_k_factor(pixels: int, N: int, ksteps: int, min_blocks: int = 384, target: int = 512) -> int:
@@ -842,7 +858,8 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
     _same_act_dtype([sv.t for sv in srcs] + [wp], "igemm_fwd(atomic)")
     K = _k(wp)
     _timed(_kernel_kind(kind, d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}")
+           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}",
+           nbytes=_nb(*[sv.t for sv in srcs], wp) + 4.0 * n_img * out_hw[0] * out_hw[1] * d.N if PROFILE is not None else 0.0)
 
 
 def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
@@ -874,7 +891,7 @@ def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor
     _same_act_dtype([h_prev, wp, h_out] + ([x] if x is not None else []) + ([gates_out] if gates_out is not None else []), "igemm_fwd(lstm)")
     K = _k(wp)
     _timed(_kernel_kind("igemm_fwd_lstm", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
-           f"M={B * H * W} N={d.N} K={d.Ktot}")
+           f"M={B * H * W} N={d.N} K={d.Ktot}", nbytes=_nb(x, h_prev, wp, c_prev, c_out, h_out, gates_out, pre_add))
 
 
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
@@ -906,6 +923,11 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
             raise L.UclstmError(f"igemm_wgrad: bad descriptor (code {splits})")
         d.splits = splits
         descs.append(d)
+    if LAUNCH_LOG is not None:
+        if len(chunks) > 1:
+            LAUNCH_LOG.append(("split", "igemm_wgrad", len(chunks)))
+        for d in descs:
+            LAUNCH_LOG.append(("wgrad", int(L.lib.uclstm_igemm_wgrad_shape(C.byref(d))), N, Ktot, int(d.splits)))
     total = sum(d.splits for d in descs)
     dwp = torch.empty((total, N, Ktot), dtype=F32, device=dev)
     taps = ktap * ktap
@@ -918,7 +940,8 @@ def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tup
         if PROFILE is not None:          # rocprofv3 names: igemm_wgrad_p3_kernel / igemm_wgrad_p2_kernel<1 or 2, nsrc> / igemm_wgrad_kernel
             kind += "[" + {4: "ring64", 3: "p3_256x256", 2: "p2_128x128", 1: "p2_64x256", 0: "generic"}.get(int(L.lib.uclstm_igemm_wgrad_shape(C.byref(d))), "?") + "]"
         _timed(kind, flops, lambda d=d: L.check(K.uclstm_igemm_wgrad(C.byref(d), _stream()), "igemm_wgrad"),
-               f"M={d.n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}")
+               f"M={d.n_img * out_hw[0] * out_hw[1]} N={N} K={Ktot} ktap={ktap} splits={d.splits}",
+               nbytes=(_nb(*[sv.t for sv in srcs], *[sg[0] for sg in dy_segs]) * (d.n_img / n_img) + 4.0 * N * Ktot) if PROFILE is not None else 0.0)
     return dwp
 
 
