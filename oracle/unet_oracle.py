@@ -46,31 +46,42 @@ class _RoundSTE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        # The storage points of the forward pass are the storage points of the backward pass too: the gradient of a stored
+        # conv output is the kernels' dz, that of a stored activation their dx -- both 16-bit tensors on the HIP path.
+        return g.to(_STORAGE_DTYPE).to(torch.float32) if _ROUND_GRADS else g
 
 
+_ROUND_GRADS = False
 _EMULATE = False
 _STORAGE_DTYPE = torch.bfloat16
+_EVAL_KEEPS_CONV_OUT = False
 
 
 class storage:
-    """Round to ``dtype`` (torch.bfloat16 / torch.float16) wherever the HIP path of that compute dtype stores."""
+    """Round to ``dtype`` (torch.bfloat16 / torch.float16) wherever the HIP path of that compute dtype stores.
 
-    def __init__(self, dtype):
-        self.dtype = dtype
+    ``eval_with_backward``: an evaluation-mode BatchNorm that WILL be differentiated through (fine-tuning with frozen
+    statistics) keeps its pre-BN convolution output in storage precision like the training path does (backward needs it),
+    whereas pure inference folds BatchNorm into the convolution epilogue and rounds once.
+
+    ``round_grads``: the gradients flowing back through the storage points are rounded as well (the kernels store dz and dx
+    in 16 bits).  The mode must still be active when ``backward()`` runs."""
+
+    def __init__(self, dtype, eval_with_backward: bool = False, round_grads: bool = False):
+        self.dtype, self.eval_bw, self.round_grads = dtype, eval_with_backward, round_grads
 
     def __enter__(self):
-        global _EMULATE, _STORAGE_DTYPE
-        self._old = (_EMULATE, _STORAGE_DTYPE)
-        _EMULATE, _STORAGE_DTYPE = True, self.dtype
+        global _EMULATE, _STORAGE_DTYPE, _EVAL_KEEPS_CONV_OUT, _ROUND_GRADS
+        self._old = (_EMULATE, _STORAGE_DTYPE, _EVAL_KEEPS_CONV_OUT, _ROUND_GRADS)
+        _EMULATE, _STORAGE_DTYPE, _EVAL_KEEPS_CONV_OUT, _ROUND_GRADS = True, self.dtype, self.eval_bw, self.round_grads
 
     def __exit__(self, *exc):
-        global _EMULATE, _STORAGE_DTYPE
-        _EMULATE, _STORAGE_DTYPE = self._old
+        global _EMULATE, _STORAGE_DTYPE, _EVAL_KEEPS_CONV_OUT, _ROUND_GRADS
+        _EMULATE, _STORAGE_DTYPE, _EVAL_KEEPS_CONV_OUT, _ROUND_GRADS = self._old
 
 
-def bf16_storage():
-    return storage(torch.bfloat16)
+def bf16_storage(eval_with_backward: bool = False, round_grads: bool = False):
+    return storage(torch.bfloat16, eval_with_backward, round_grads)
 
 
 def fp16_storage():
@@ -80,6 +91,22 @@ def fp16_storage():
 
 def _q(t: Tensor) -> Tensor:
     return _RoundSTE.apply(t) if _EMULATE else t
+
+
+class _RoundWeight(torch.autograd.Function):
+    """Weights are packed into 16-bit panels, their GRADIENTS stay f32 (f32 slabs -> f32 .grad)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(_STORAGE_DTYPE).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _qw(t: Tensor) -> Tensor:
+    return _RoundWeight.apply(t) if _EMULATE else t
 
 
 # ---------------------------------------------------------------------------
@@ -100,7 +127,7 @@ def convlstm_cell(x: Tensor, h: Optional[Tensor], c: Optional[Tensor],
     if h is None:
         h = x.new_zeros(B, hd, H, W)
         c = x.new_zeros(B, hd, H, W)
-    pre = F.conv2d(torch.cat((_q(x), _q(h)), dim=1), _q(weight), bias, padding=k // 2)
+    pre = F.conv2d(torch.cat((_q(x), _q(h)), dim=1), _qw(weight), bias, padding=k // 2)
     pi, pf, pg, po = pre[:, 0:hd], pre[:, hd:2 * hd], pre[:, 2 * hd:3 * hd], pre[:, 3 * hd:4 * hd]
     gi = 1.0 / (1.0 + torch.exp(-pi))
     gf = 1.0 / (1.0 + torch.exp(-pf))
@@ -162,6 +189,8 @@ def batchnorm_relu(z: Tensor, p: Params, prefix: str, training: bool,
             buffers_out[f"{prefix}.running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * unbiased
             buffers_out[f"{prefix}.num_batches_tracked"] = nb + 1
     else:
+        if _EVAL_KEEPS_CONV_OUT:
+            z = _q(z)
         src = p if buffers_out is None else {**p, **buffers_out}
         mean, var = src[f"{prefix}.running_mean"], src[f"{prefix}.running_var"]
     xhat = (z - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
@@ -171,20 +200,22 @@ def batchnorm_relu(z: Tensor, p: Params, prefix: str, training: bool,
 def double_conv(x: Tensor, p: Params, prefix: str, training: bool,
                 buffers_out: Optional[Params]) -> Tensor:
     """(conv3x3 pad1 + bias -> BN -> ReLU) x2, train/unet.py:66-75 (Sequential indices 0,1,3,4)."""
-    z = F.conv2d(_q(x), _q(p[f"{prefix}.net.0.weight"]), p[f"{prefix}.net.0.bias"], padding=1)
+    z = F.conv2d(_q(x), _qw(p[f"{prefix}.net.0.weight"]), p[f"{prefix}.net.0.bias"], padding=1)
     a = batchnorm_relu(z, p, f"{prefix}.net.1", training, buffers_out)
-    z = F.conv2d(a, _q(p[f"{prefix}.net.3.weight"]), p[f"{prefix}.net.3.bias"], padding=1)
+    z = F.conv2d(a, _qw(p[f"{prefix}.net.3.weight"]), p[f"{prefix}.net.3.bias"], padding=1)
     return batchnorm_relu(z, p, f"{prefix}.net.4", training, buffers_out)
 
 
 def down(x: Tensor, p: Params, prefix: str, training: bool, buffers_out) -> Tensor:
     """MaxPool2d(2) then DoubleConv, train/unet.py:78-84 (keys ``<prefix>.net.1.net.N``)."""
-    return double_conv(F.max_pool2d(x, 2), p, f"{prefix}.net.1", training, buffers_out)
+    # storage emulation: the HIP path pools the STORED (rounded) tensor -- same values as rounding after the pool, but ties of
+    # rounded values route the gradient to the first maximum in scan order (ATen's rule, which the kernel reproduces)
+    return double_conv(F.max_pool2d(_q(x), 2), p, f"{prefix}.net.1", training, buffers_out)
 
 
 def up(x1: Tensor, x2: Tensor, p: Params, prefix: str, training: bool, buffers_out) -> Tensor:
     """ConvTranspose2d(k2,s2) -> pad to skip size -> cat([skip, up]) -> DoubleConv, train/unet.py:87-98."""
-    u = _q(F.conv_transpose2d(_q(x1), _q(p[f"{prefix}.up.weight"]), p[f"{prefix}.up.bias"], stride=2))
+    u = _q(F.conv_transpose2d(_q(x1), _qw(p[f"{prefix}.up.weight"]), p[f"{prefix}.up.bias"], stride=2))
     dy = x2.shape[2] - u.shape[2]
     dx = x2.shape[3] - u.shape[3]
     u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])     # :95-97

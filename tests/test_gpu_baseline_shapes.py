@@ -110,9 +110,9 @@ def check_case(name, expect_kernels=(), check_grads=True):
         # autocast drift, and the norm against the reference's per-tensor norm
         names = [k for k, _ in model.named_parameters()]
         assert names == [str(n) for n in g["grad_names"]]
-        bad, rows = per_tensor_grad_report(names, {k: p.grad.cpu() for k, p in model.named_parameters()}, rg,
-                                           [float(v) for v in g["grad_norms"]], [float(v) for v in g["ac_grad_rel_l2_per_tensor"]])
-        print(f"[parity] {name}: per-tensor gradients, worst five of {len(rows)} (rel-L2 / bound): " +
+        bad, rows, med = per_tensor_grad_report(names, {k: p.grad.cpu() for k, p in model.named_parameters()}, rg,
+                                                [float(v) for v in g["grad_norms"]], [float(v) for v in g["ac_grad_rel_l2_per_tensor"]])
+        print(f"[parity] {name}: per-tensor gradients: median rel-L2 / reference-autocast drift {med:.3f} (bound 1.25); worst five of {len(rows)} (rel-L2 / bound): " +
               "; ".join(f"{k} {rel:.4f}/{bound:.4f}" for _, k, rel, bound, _, z in rows[:5] if not z))
         assert not bad, f"{name}: " + " | ".join(bad[:8])
     return g, model, xd
@@ -273,9 +273,11 @@ def test_config1_full_size_properties():
 # images wider than 64 pixels, the 256 x 256 / 8-phase weight gradient, the ring kernels, and the launch splitting at the
 # 2-GiB descriptor range run HERE and nowhere else in the suite at real sizes.
 # ---------------------------------------------------------------------------------------------
-def _full_size_properties(size, T, B, dtype, indep=(0,), roll_b=2, train_tol=1e-6, seed=31):
+def _full_size_properties(size, T, B, dtype, indep=(0,), roll_b=2, train_tol=5e-6, seed=31):
     """(a) a training step run twice from the same state gives the same loss and, to f32 rounding, the same gradient (no float
-    atomics); (b) eval-mode batch independence: sample b inside the batch == that sample alone (different kernel plans);
+    atomics on the GEMM / BatchNorm paths; the bias column sums end in one f32 atomic per block: 1e-6 on those tensors.  This
+    check found a write-after-read race in the two ring kernels at strip boundaries in round 3 -- one tensor off by
+    1e-4 .. 6e-4 in a third of the processes at 256 x 256, profiles/round3_notes.md); (b) eval-mode batch independence: sample b inside the batch == that sample alone (different kernel plans);
     (c) the stateful frame-by-frame rollout (HIP graph) == the full-sequence forward.  Returns the launch log of (a)."""
     torch.manual_seed(seed)
     with ops.compute_dtype(dtype):
@@ -292,7 +294,10 @@ def _full_size_properties(size, T, B, dtype, indep=(0,), roll_b=2, train_tol=1e-
                 log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
             runs.append((float(loss), opt.flat.flat_g.detach().clone()))
         d = rel_l2(runs[1][1].cpu(), runs[0][1].cpu())
-        print(f"[parity] {size}x{size} T={T} B={B} {dtype}: step twice: loss {runs[0][0]:.6f} / {runs[1][0]:.6f}, gradient rel-L2 {d:.2e}")
+        worst = sorted(((rel_l2(runs[1][1][o:o + p.numel()].cpu(), runs[0][1][o:o + p.numel()].cpu()), k)
+                        for (k, p), o in zip(model.named_parameters(), opt.flat.offsets)), reverse=True)[:4]
+        print(f"[parity] {size}x{size} T={T} B={B} {dtype}: step twice: loss {runs[0][0]:.6f} / {runs[1][0]:.6f}, gradient rel-L2 {d:.2e}; "
+              f"least reproducible tensors {[(k, float(f'{e:.1e}')) for e, k in worst]}")
         assert runs[0][0] == runs[1][0] and d <= train_tol and bool(torch.isfinite(runs[0][1]).all()) and float(runs[0][1].abs().max()) > 0
         model.eval()
         with torch.no_grad():
@@ -329,7 +334,7 @@ def test_config2_full_size_properties():
 def test_config3_full_size_properties(dtype):
     """BASELINE configs[3]: 256x256 seq-12, per-GPU batch 4, 4-level UNet-ConvLSTM at base_ch 64, bf16 and the fp16-MFMA twins.
     The 128x128 level has C = 128: the strip-mode patch tiles (4-row x 64-column blocks of one image) run here."""
-    log = _full_size_properties(256, 12, 4, dtype, indep=(0, 3), roll_b=2, train_tol=1e-6 if dtype == torch.bfloat16 else 1e-5)
+    log = _full_size_properties(256, 12, 4, dtype, indep=(0, 3), roll_b=2)
     assert _fwd(log, 0, 2, 128), f"strip-mode patch loop (images wider than 64 pixels, C_out >= 128) not exercised: {sorted(set(log))[:12]}"
     assert any(r[0] == "wgrad" and r[1] == 3 for r in log), "256 x 256 / 8-phase weight gradient not exercised"
 
@@ -353,7 +358,10 @@ def test_config3_reference_batch_is_cut_at_the_descriptor_range():
     splits = [r for r in log if r[0] == "split"]
     print(f"[parity] 256x256 B=32 T=8: split launches {sorted(set(splits))}; loss {runs[0][0]:.6f} / {runs[1][0]:.6f}")
     assert any(r[1] == "igemm_fwd(store)" for r in splits) and any(r[1] == "igemm_wgrad" for r in splits)
-    assert runs[0][0] == runs[1][0] and rel_l2(runs[1][1].cpu(), runs[0][1].cpu()) <= 1e-6 and bool(torch.isfinite(runs[0][1]).all())
+    worst = sorted(((rel_l2(runs[1][1][o:o + p.numel()].cpu(), runs[0][1][o:o + p.numel()].cpu()), k)
+                    for (k, p), o in zip(model.named_parameters(), opt.flat.offsets)), reverse=True)[:4]
+    print(f"[parity] 256x256 B=32 T=8: least reproducible tensors {[(k, float(f'{e:.1e}')) for e, k in worst]}")
+    assert runs[0][0] == runs[1][0] and rel_l2(runs[1][1].cpu(), runs[0][1].cpu()) <= 5e-6 and bool(torch.isfinite(runs[0][1]).all())
     del runs, opt
     model.eval()
     with torch.no_grad():

@@ -738,8 +738,11 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].ptr, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.wp, 0, (uint32_t)(64 * 576 * 2), 0x00020000);
 
-    // permanent zero halo columns (positions 0 and 65 of every ring row)
-    if (tid < C64_SLOTS * 2 * 8) {
+    // permanent zero halo columns (positions 0 and 65 of every ring row) -- only when the image is one strip wide: with more
+    // strips every staged row brings its halo pixels by DMA (real pixels or out-of-range zeros), and a plain store here would
+    // race with the first of those DMAs (no ordering between one wave's ds_write and another wave's LDS-DMA before the first
+    // barrier; see igemm_wgrad_c64_kernel)
+    if ((d.W >> 6) == 1 && tid < C64_SLOTS * 2 * 8) {
         const int sl = tid >> 4, side = (tid >> 3) & 1, ch = tid & 7;
         *(uint4*)(Ring + sl * C64_ROW + side * 65 * 128 + ch * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -847,7 +850,11 @@ __global__ __launch_bounds__(256, 1) void igemm_fwd_c64_kernel(const uclstm_igem
             lslot = (v + 1) % C64_SLOTS;
             loaded = v - 1;
         }
-        // rows this tile needs that were not prefetched (six at the start of the block, one after an image boundary)
+        // rows this tile needs that were not prefetched (six at the start of the block, one after an image boundary).  The one
+        // after a boundary lands in the slot of the PREVIOUS tile's first row, which a slower wave may still be reading (there
+        // is no barrier inside a tile, and with another kernel sharing the CU the waves drift): wait for everybody first.  The
+        // condition is block-uniform; it holds once per image strip.
+        if (tt != t_begin && loaded < v0 + 4) __syncthreads();
         while (loaded < v0 + 4) C64_ISSUE_NEXT_ROW()
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -829,8 +829,12 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_c64_kernel(const uclstm_wg
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)G.ptr, 0, ybytes, 0x00020000);
 
-    // zero the halo columns (ring positions 0 and 65 of every slot) once: permanent when the image is one strip wide
-    if (tid < WR_SLOTS * 2 * 8) {
+    // zero the halo columns (ring positions 0 and 65 of every slot) once: permanent when the image is one strip wide.
+    // With more than one strip EVERY staged row brings its halo pixels by DMA (real pixels or out-of-range zeros), and these
+    // plain stores must not exist: nothing orders a ds_write of wave 2 against the first halo DMAs of waves 0 / 1 to the same
+    // bytes (different counters, no barrier in between) -- a late wave zeroed halo pixels that had already landed, ~1 in 4
+    // processes, one tensor off by 1e-4 .. 6e-4 (found by the 256 x 256 reproducibility test of round 3).
+    if (strips == 1 && tid < WR_SLOTS * 2 * 8) {
         const int sl = tid >> 4, side = (tid >> 3) & 1, ch = tid & 7;
         *(uint4*)(Ring + sl * WR_PITCH + side * 65 * 128 + ch * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -926,6 +930,11 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_c64_kernel(const uclstm_wg
             lslot = (v + 1) % WR_SLOTS;
             loaded = v - 1;
         }
+        // After a strip boundary ONE row was not prefetched (the look-ahead is capped at the four free slots); it lands in the
+        // slot of the previous tile's first row, which a slower wave may still be reading -- no barrier inside a tile, and on
+        // the weight-gradient stream another kernel shares the CU, so the waves drift (seen as one tensor off by 1e-4 .. 6e-4
+        // in ~1 of 3 processes at 256 x 256).  Everybody first; block-uniform condition, once per image strip.
+        if (tt != t_begin && loaded < v0 + 4) __syncthreads();
         while (loaded < v0 + 4) WR_ISSUE_NEXT_ROW()
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
