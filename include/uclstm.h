@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 12
+#define UCLSTM_ABI_VERSION 13
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -123,8 +123,19 @@ int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* d, void* stream);
  * rows); 3 = the 64 -> 64-channel ring kernel.  Negative: UCLSTM_E_*.  Tests use it to assert that a parity case really
  * exercised the kernel it is meant for. */
 int32_t uclstm_igemm_fwd_shape(const uclstm_igemm_desc* desc);
-/* Number of non-empty K ranges uclstm_igemm_fwd will use for (Ktot, requested ksplit): the slab count of acc_slab mode. */
-int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit);
+/* Number of non-empty K ranges uclstm_igemm_fwd will use for (Ktot, kernel width, requested ksplit): the slab count of acc_slab
+ * mode.  K ranges are whole (source, 64-channel) chunks of ktap*ktap K-steps: steps per range = ktap^2 * ceil(chunks / ksplit). */
+int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ktap, int32_t ksplit);
+
+/* n (1..4) INDEPENDENT descriptors as ONE launch: the per-timestep gate convolutions of the model's three ConvLSTMs
+ * (bottleneck + two skip LSTMs, train/unet.py:185-191 runs them one after the other) each fill the chip for one or two rounds of
+ * blocks only; as one grid -- members ordered longest block first -- their drains and fills overlap.  Every member must be a
+ * descriptor uclstm_igemm_fwd would run on the patch shape (uclstm_igemm_fwd_shape == 2) with UCLSTM_EPI_LSTM or UCLSTM_EPI_ATOMIC
+ * (slab mode), all with the same nsrc; anything else is UCLSTM_E_BADARG and the caller launches the members one by one.
+ * Results are bit-identical to n separate uclstm_igemm_fwd launches. */
+int32_t uclstm_igemm_fwd_group(const uclstm_igemm_desc* descs, int32_t n, void* stream);
+/* Validation only: the block count of the launch uclstm_igemm_fwd_group would make (>= 1), or UCLSTM_E_*. */
+int32_t uclstm_igemm_fwd_group_blocks(const uclstm_igemm_desc* descs, int32_t n);
 
 /* Weight gradient  dWp[n][k] (+)= sum_pixels dY[pixel][n] * A[pixel][k]  (f32 [N][Ktot], same
  * K order as the forward panel).  dY is read through seg[] (nseg >= 1); `splits` pixel ranges
@@ -286,6 +297,21 @@ int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab /* pre-activation = 
                                   const float* pre_add /* f32 [pixels][N] or NULL: added to the slabs (hoisted W_x * x_t) */,
                                   const float* bias, const float* c_prev, float* c_out, void* h_out,
                                   void* gates_out, int64_t pixels, int32_t Hd_p, void* stream);
+/* n (1..4) independent cells in one launch (the model's three ConvLSTMs advance in lockstep in the forward pass,
+ * uclstm_igemm_fwd_group); fields as the arguments above. */
+typedef struct {
+    float* pre;
+    const float* pre_add;
+    const float* bias;
+    const float* c_prev;
+    float* c_out;
+    void* h_out;
+    void* gates_out;
+    int64_t slab;
+    int64_t pixels;
+    int32_t nslab, clear, Hd_p, reserved_;
+} uclstm_lstm_fwd_pw_args;
+int32_t uclstm_lstm_fwd_pointwise_group(const uclstm_lstm_fwd_pw_args* args, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Layout / boundary kernels                                                            */
@@ -394,6 +420,7 @@ int32_t uclstm_stream_spin(int32_t microseconds, void* stream);
  * a second backend. */
 #define UCLSTM_F16_TWIN(fn) __typeof__(fn) fn##_f16;
 UCLSTM_F16_TWIN(uclstm_igemm_fwd)
+UCLSTM_F16_TWIN(uclstm_igemm_fwd_group)
 UCLSTM_F16_TWIN(uclstm_igemm_wgrad)
 UCLSTM_F16_TWIN(uclstm_pack_weights)
 UCLSTM_F16_TWIN(uclstm_pack_weights_batched)
@@ -404,6 +431,7 @@ UCLSTM_F16_TWIN(uclstm_maxpool2_fwd)
 UCLSTM_F16_TWIN(uclstm_maxpool2_bwd)
 UCLSTM_F16_TWIN(uclstm_lstm_bwd_pointwise)
 UCLSTM_F16_TWIN(uclstm_lstm_fwd_pointwise)
+UCLSTM_F16_TWIN(uclstm_lstm_fwd_pointwise_group)
 UCLSTM_F16_TWIN(uclstm_splitk_finish)
 UCLSTM_F16_TWIN(uclstm_nchw_to_nhwc)
 UCLSTM_F16_TWIN(uclstm_nhwc_to_nchw)

@@ -392,3 +392,47 @@ def test_config4_full_size_properties():
           f"max |diff| {float((a - b).abs().max()):.1e}")
     assert torch.equal(a, b), "graph replay differs from eager frame-by-frame"
     assert e <= 5e-3 and m <= EVAL_MR_CAP and bool(torch.isfinite(a).all())
+
+
+def test_grouped_recurrence_matches_separate_launches():
+    """The three ConvLSTMs as ONE group launch per timestep (ops.ConvLSTMGroup, uclstm_igemm_fwd_group) against the three
+    sequences of launches (ops.ConvLSTMSeq): same arithmetic, only the K-range counts differ (f32 summation order of the split-K
+    slabs), at the benchmark's width and batch."""
+    torch.manual_seed(77)
+    model = U.TemporalUNetDualView(1, 1, base_ch=64, use_skip_lstm=True).to(DEV)
+    data = U.SyntheticSequences(32, 3, 64, 64, seed=78, kind="uniform")
+    res = {}
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for grouped in (True, False):
+        model.load_state_dict(sd0)          # the train-mode forward below moves the running statistics
+        ops.GROUP_LSTM = grouped
+        try:
+            ops.KERNEL_LOG = []
+            model.eval()
+            with torch.no_grad():
+                outs, st = model(data.x)
+            ev = torch.stack(outs, 1).cpu()
+            model.train()
+            model.zero_grad(set_to_none=True)
+            outs, _ = model(data.x)
+            loss = U.compute_loss(torch.stack(outs, 1), data.y, data.mask, True)
+            loss.backward()
+            torch.cuda.synchronize()
+            log = list(ops.KERNEL_LOG)
+        finally:
+            ops.KERNEL_LOG = None
+            ops.GROUP_LSTM = True
+        res[grouped] = (ev, st[0][0].cpu(), st[0][1].cpu(), float(loss), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}, log)
+    a, b = res[True], res[False]
+    assert (1, 2) in a[5] and (2, 2) in a[5]
+    e_out, e_h, e_c = max(per_t(a[0], b[0])), rel_l2(a[1], b[1]), rel_l2(a[2], b[2])
+    e_mr = max(mr_rel_l2_per_t(a[0], b[0]))
+    worst = sorted(((rel_l2(a[4][k], b[4][k]), k) for k in a[4] if float(b[4][k].abs().max()) > 0), reverse=True)[:4]
+    print(f"[parity] grouped vs separate recurrence launches: eval outputs {e_out:.2e} (mean-removed {e_mr:.2e}), final h {e_h:.2e}, c {e_c:.2e}; "
+          f"train loss {a[3]:.6f} / {b[3]:.6f}; worst gradients {[(k, float(f'{e:.1e}')) for e, k in worst]}")
+    assert e_out <= 1e-3 and e_mr <= 2e-2 and e_h <= 5e-3 and e_c <= 5e-3
+    assert abs(a[3] - b[3]) <= 2e-4 * abs(b[3])
+    fa = torch.cat([a[4][k].flatten() for k in a[4]])
+    fb = torch.cat([b[4][k].flatten() for k in a[4]])
+    print(f"[parity] grouped vs separate: whole gradient rel-L2 {rel_l2(fa, fb):.4f}")
+    assert rel_l2(fa, fb) <= 5e-2

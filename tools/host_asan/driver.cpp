@@ -87,7 +87,7 @@ int main() {
             return 1;
         }
         (shp >= 0 ? n_ok : n_bad)++;
-        if (d.Ktot > 0) (void)uclstm_igemm_ksplit_used(d.Ktot, d.ksplit);
+        if (d.Ktot > 0) (void)uclstm_igemm_ksplit_used(d.Ktot, d.ktap, d.ksplit);
         if (d.n_img > 0 && d.groups > 0) (void)uclstm_igemm_tiles_per_group(d.n_img, d.H, d.W, d.groups, d.N);
 
         uclstm_wgrad_desc w;

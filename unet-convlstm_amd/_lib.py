@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -66,6 +66,12 @@ class WgradDesc(C.Structure):
                 ("slab", C.c_int64)]
 
 
+class LstmFwdPwArgs(C.Structure):
+    _fields_ = [("pre", C.c_void_p), ("pre_add", C.c_void_p), ("bias", C.c_void_p), ("c_prev", C.c_void_p), ("c_out", C.c_void_p),
+                ("h_out", C.c_void_p), ("gates_out", C.c_void_p), ("slab", C.c_int64), ("pixels", C.c_int64),
+                ("nslab", C.c_int32), ("clear", C.c_int32), ("Hd_p", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("Ktot", C.c_int32), ("taps", C.c_int32), ("nsrc", C.c_int32),
                 ("kseg", C.c_int32 * 2), ("cvalid", C.c_int32 * 2), ("choff", C.c_int32 * 2),
@@ -89,7 +95,9 @@ _PROTOS = {
     "uclstm_igemm_tiles_per_group": [_I, _I, _I, _I, _I],
     "uclstm_igemm_fwd": [C.POINTER(IgemmDesc), _P],
     "uclstm_igemm_fwd_shape": [_P],
-    "uclstm_igemm_ksplit_used": [_I, _I],
+    "uclstm_igemm_ksplit_used": [_I, _I, _I],
+    "uclstm_igemm_fwd_group": [C.POINTER(IgemmDesc), _I, _P],
+    "uclstm_igemm_fwd_group_blocks": [C.POINTER(IgemmDesc), _I],
     "uclstm_igemm_wgrad": [C.POINTER(WgradDesc), _P],
     "uclstm_igemm_wgrad_splits": [C.POINTER(WgradDesc)],
     "uclstm_igemm_wgrad_shape": [C.POINTER(WgradDesc)],
@@ -110,6 +118,7 @@ _PROTOS = {
     "uclstm_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "uclstm_lstm_bwd_pointwise": [_P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P, _L, _I, _P],
     "uclstm_lstm_fwd_pointwise": [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "uclstm_lstm_fwd_pointwise_group": [C.POINTER(LstmFwdPwArgs), _I, _P],
     "uclstm_splitk_finish": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _L, _I, _P],
     "uclstm_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _P],
     "uclstm_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -140,7 +149,7 @@ _RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_source_hash": C.c_char_p, 
 
 
 # entry points that exist twice: name (bfloat16) and name_f16 (IEEE binary16), identical signatures (include/uclstm.h)
-F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_pack_weights_batched', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_splitk_finish', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
+F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_fwd_group', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_pack_weights_batched', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_lstm_fwd_pointwise_group', 'uclstm_splitk_finish', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
 
 
 def header_symbols() -> list[str]:

@@ -10,6 +10,7 @@
 // f32 in both.  Entry points that do not touch 16-bit data exist once (guarded by #ifndef UCLSTM_ACT_F16 in their files).
 #if defined(UCLSTM_ACT_F16)
 #define uclstm_igemm_fwd uclstm_igemm_fwd_f16
+#define uclstm_igemm_fwd_group uclstm_igemm_fwd_group_f16
 #define uclstm_igemm_wgrad uclstm_igemm_wgrad_f16
 #define uclstm_pack_weights uclstm_pack_weights_f16
 #define uclstm_pack_weights_batched uclstm_pack_weights_batched_f16
@@ -21,6 +22,7 @@
 #define uclstm_maxpool2_bwd uclstm_maxpool2_bwd_f16
 #define uclstm_lstm_bwd_pointwise uclstm_lstm_bwd_pointwise_f16
 #define uclstm_lstm_fwd_pointwise uclstm_lstm_fwd_pointwise_f16
+#define uclstm_lstm_fwd_pointwise_group uclstm_lstm_fwd_pointwise_group_f16
 #define uclstm_nchw_to_nhwc uclstm_nchw_to_nhwc_f16
 #define uclstm_nhwc_to_nchw uclstm_nhwc_to_nchw_f16
 #define uclstm_nchw_grad_to_nhwc uclstm_nchw_grad_to_nhwc_f16

@@ -93,8 +93,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // KT = widest kernel the per-tap loop's tap masks cover: 3 (one 32-bit word, the hot path) or 7 (two words: ConvLSTM cells
 // with 5x5 / 7x7 gate convolutions, 128 x 128 shape only).
+// The kernel body as a device function of (descriptor, derived constants, block id within this launch plan): the plain
+// kernel below passes blockIdx.x, the grouped kernel (several independent GEMMs in ONE launch) the block's index inside its
+// member's sub-grid.
 template <int EPI, int SHP, int NSRC, int KT = 3>
-__global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+__device__ __forceinline__ void igemm_fwd_body(const uclstm_igemm_desc& d, const Derived& dv, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type does not exist in the host pass (the stub needs no body)
     using SH = Shape<SHP>;
     constexpr int TBN = SH::TBN, TBM = SH::TBM, XR = SH::XR, WR = SH::WR, NT = SH::NT, RS = SH::RS;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
     const int lq = lane >> 4;
 
     const int per_split = dv.n_mtiles * dv.n_ntiles;
-    const int lid0 = xcd_remap(blockIdx.x, per_split * dv.ksplit);
+    const int lid0 = xcd_remap(bid, per_split * dv.ksplit);
     const int ks = lid0 / per_split;                 // K range of this block (0 unless split-K)
     const int lid = lid0 - ks * per_split;
     int nt, mt;
@@ -693,6 +696,47 @@ __global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_ke
 #endif
 }
 
+template <int EPI, int SHP, int NSRC, int KT = 3>
+__global__ __launch_bounds__(Shape<SHP>::NT, Shape<SHP>::MINB) void igemm_fwd_kernel(const uclstm_igemm_desc d, const Derived dv) {
+    igemm_fwd_body<EPI, SHP, NSRC, KT>(d, dv, (int)blockIdx.x);
+}
+
+// ---- several independent GEMMs of the patch shape in ONE launch ------------------------------------------------------
+// The three ConvLSTMs of the model (bottleneck + two skip LSTMs, train/unet.py:185-191) are independent recurrences whose
+// per-timestep GEMMs each fill the 256 CUs for one or two rounds only; launched one after the other every one of them pays
+// its own drain and fill.  A group launch is one grid whose block ranges belong to different descriptors (members ordered by
+// the host longest block first: the hardware hands out blocks in id order, i.e. longest-processing-time-first scheduling), each
+// with its own epilogue (fused cell update or split-K slabs).  A member's first block id is a multiple of 8 so that its
+// XCD-aware tile order is what a launch of its own would have.
+constexpr int GROUP_MAX = 4;
+struct FwdGroup {
+    int n;
+    int first[GROUP_MAX + 1];      // block ranges [first[i], first[i+1]); blocks beyond a member's own count do nothing
+    int nblk[GROUP_MAX];
+    uclstm_igemm_desc d[GROUP_MAX];
+    Derived dv[GROUP_MAX];
+};
+
+template <int NSRC>
+__global__ __launch_bounds__(Shape<2>::NT, 1) void igemm_fwd_group_kernel(const FwdGroup g) {
+    const int b = (int)blockIdx.x;
+    // constant member index in every access: all fields are read straight from the kernel-argument segment (a runtime index
+    // into the by-value struct would send the whole 2-KiB argument to scratch memory)
+#define UCLSTM_GROUP_MEMBER(j_)                                                                            \
+    if (j_ < g.n && b >= g.first[j_] && b < g.first[j_ + 1]) {                                             \
+        const int bid = b - g.first[j_];                                                                   \
+        if (bid >= g.nblk[j_]) return;                                                                     \
+        if (g.d[j_].epi == UCLSTM_EPI_LSTM) igemm_fwd_body<UCLSTM_EPI_LSTM, 2, NSRC>(g.d[j_], g.dv[j_], bid);   \
+        else igemm_fwd_body<UCLSTM_EPI_ATOMIC, 2, NSRC>(g.d[j_], g.dv[j_], bid);                           \
+        return;                                                                                            \
+    }
+    UCLSTM_GROUP_MEMBER(0)
+    UCLSTM_GROUP_MEMBER(1)
+    UCLSTM_GROUP_MEMBER(2)
+    UCLSTM_GROUP_MEMBER(3)
+#undef UCLSTM_GROUP_MEMBER
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // 3x3 / pad 1 convolution with C_in = C_out = 64 on images whose width is a multiple of 64 (the full-resolution level of
 // the UNet; at the 64x64 configurations: 2.6 M pixels, K = 576 -- nine K-steps per tile, where the generic kernel spends as long in its
@@ -1084,11 +1128,17 @@ extern "C" int32_t uclstm_igemm_tiles_per_group(int32_t n_img, int32_t H, int32_
 }
 #endif
 
+// K ranges of a split-K launch are whole (source, 64-channel) CHUNKS -- ktap*ktap consecutive K-steps -- so that every range
+// can run the patch loop (a chunk's activations are staged once for all its taps): steps per range = taps * ceil(chunks / ksplit).
+static inline int ksplit_kper(int ksteps, int taps, int ksplit) {
+    const int chunks = ksteps / taps;
+    return taps * ((chunks + ksplit - 1) / ksplit);
+}
 #ifndef UCLSTM_ACT_F16
-extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ksplit) {
-    if (Ktot <= 0 || (Ktot % BK) || ksplit < 1) return UCLSTM_E_BADARG;
+extern "C" int32_t uclstm_igemm_ksplit_used(int32_t Ktot, int32_t ktap, int32_t ksplit) {
+    if (Ktot <= 0 || (Ktot % BK) || ksplit < 1 || ktap < 1 || ktap > 7 || (Ktot / BK) % (ktap * ktap)) return UCLSTM_E_BADARG;
     const int ksteps = Ktot / BK;
-    const int kper = (ksteps + ksplit - 1) / ksplit;
+    const int kper = ksplit_kper(ksteps, ktap * ktap, ksplit);
     return (ksteps + kper - 1) / kper;
 }
 #endif
@@ -1126,11 +1176,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     shp = d.ktap > 3 ? 0 : pick_shape(d.N, mg, d.groups, d.epi);      // kernels wider than 3x3: the 128 x 128 shape only
     mg_out = mg;
     int patch = patch_ok(d, mg);
-    if (patch && d.epi == UCLSTM_EPI_ATOMIC) {            // K ranges must be whole 64-channel chunks (9 taps each)
-        if (d.ksplit < 1) return UCLSTM_E_BADARG;
-        const int kper = (d.Ktot / BK + d.ksplit - 1) / d.ksplit;
-        if ((kper % 9) != 0) patch = 0;
-    }
+    if (d.epi == UCLSTM_EPI_ATOMIC && d.ksplit < 1) return UCLSTM_E_BADARG;      // (K ranges are whole chunks: ksplit_kper)
     if (patch) shp = 2;
     dv.strip = patch == 2;
     dv.strips = d.W / 64;
@@ -1147,7 +1193,7 @@ static int32_t plan_fwd(const uclstm_igemm_desc& d, Derived& dv, int& shp, int64
     if (d.epi == UCLSTM_EPI_ATOMIC) {
         if (!d.acc_out || d.acc_ld < d.N || d.ksplit < 1 || d.acc_slab < 0) return UCLSTM_E_BADARG;
         if (d.acc_slab > 0 && d.acc_slab < mg * d.groups * (int64_t)d.acc_ld) return UCLSTM_E_BADARG;
-        dv.kper = (dv.ksteps + d.ksplit - 1) / d.ksplit;
+        dv.kper = ksplit_kper(dv.ksteps, taps, d.ksplit);
         dv.ksplit = (dv.ksteps + dv.kper - 1) / dv.kper;      // every K range is non-empty
     }
     nblk = (int64_t)dv.n_mtiles * dv.n_ntiles * dv.ksplit;
@@ -1217,3 +1263,57 @@ extern "C" int32_t uclstm_igemm_fwd(const uclstm_igemm_desc* dp, void* stream) {
     if (shp == 1) return launch<UCLSTM_EPI_STORE, 1>(d, dv, nblk, st);
     return launch<UCLSTM_EPI_STORE, 0>(d, dv, nblk, st);
 }
+
+// Several independent GEMMs in one launch (igemm_fwd_group_kernel).  Every member must be a descriptor that uclstm_igemm_fwd
+// would run on the patch shape (uclstm_igemm_fwd_shape == 2) with the fused-cell or the split-K epilogue, and all members must
+// have the same number of sources.  query != 0: validate only and return the block count of the launch.
+static int32_t fwd_group_run(const uclstm_igemm_desc* descs, int32_t n, void* stream, int query) {
+    if (!descs || n < 1 || n > GROUP_MAX) return UCLSTM_E_BADARG;
+    FwdGroup g{};
+    int64_t work[GROUP_MAX];
+    int order[GROUP_MAX];
+    Derived dvs[GROUP_MAX];
+    int64_t nblks[GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const uclstm_igemm_desc& d = descs[i];
+        int shp = 0;
+        int64_t mg = 0;
+        const int32_t rc = plan_fwd(d, dvs[i], shp, nblks[i], mg);
+        if (rc != UCLSTM_OK) return rc;
+        if (shp != 2 || (c64_ok(d) && mg % 256 == 0)) return UCLSTM_E_BADARG;
+        if (d.epi != UCLSTM_EPI_LSTM && d.epi != UCLSTM_EPI_ATOMIC) return UCLSTM_E_BADARG;
+        if (d.nsrc != descs[0].nsrc) return UCLSTM_E_BADARG;
+        work[i] = dvs[i].kper;              // K-steps per block: longest blocks get the lowest block ids
+        order[i] = i;
+    }
+    for (int a = 1; a < n; ++a)             // insertion sort, stable, descending work
+        for (int b = a; b > 0 && work[order[b]] > work[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    g.n = n;
+    int64_t at = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        g.first[k] = (int)at;
+        g.nblk[k] = (int)nblks[i];
+        g.d[k] = descs[i];
+        g.dv[k] = dvs[i];
+        at += (nblks[i] + 7) / 8 * 8;
+        if (at > 0x7fffffff) return UCLSTM_E_BADARG;
+    }
+    for (int k = n; k <= GROUP_MAX; ++k) g.first[k] = (int)at;
+    if (query) return (int32_t)at;
+    hipStream_t st = (hipStream_t)stream;
+    if (descs[0].nsrc == 1) {
+        static bool a1 = false;
+        if (!a1) { (void)hipFuncSetAttribute((const void*)igemm_fwd_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<2>::SMEM); a1 = true; }
+        UCLSTM_LAUNCH((igemm_fwd_group_kernel<1>), dim3((unsigned)at), dim3(Shape<2>::NT), Shape<2>::SMEM, st, g);
+    } else {
+        static bool a2 = false;
+        if (!a2) { (void)hipFuncSetAttribute((const void*)igemm_fwd_group_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<2>::SMEM); a2 = true; }
+        UCLSTM_LAUNCH((igemm_fwd_group_kernel<2>), dim3((unsigned)at), dim3(Shape<2>::NT), Shape<2>::SMEM, st, g);
+    }
+    return UCLSTM_OK;
+}
+extern "C" int32_t uclstm_igemm_fwd_group(const uclstm_igemm_desc* descs, int32_t n, void* stream) { return fwd_group_run(descs, n, stream, 0); }
+#ifndef UCLSTM_ACT_F16
+extern "C" int32_t uclstm_igemm_fwd_group_blocks(const uclstm_igemm_desc* descs, int32_t n) { return fwd_group_run(descs, n, nullptr, 1); }
+#endif

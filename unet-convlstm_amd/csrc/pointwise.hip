@@ -475,11 +475,11 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 // ---------------------------------------------------------------------------------------------
 // Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
 // (n = hb*64 + gate*16 + j <-> hidden channel hb*16 + j).  One thread = 4 hidden channels of one pixel.
-__global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ pre_add,
-                                   const float* __restrict__ bias,
-                                   const float* __restrict__ c_prev, float* __restrict__ c_out, act16* __restrict__ h_out,
-                                   act16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * NT) {
+__device__ __forceinline__ void lstm_fwd_pw_body(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ pre_add,
+                                                 const float* __restrict__ bias,
+                                                 const float* __restrict__ c_prev, float* __restrict__ c_out, act16* __restrict__ h_out,
+                                                 act16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N, int blk, int nblk) {
+    for (int64_t idx = (int64_t)blk * NT + threadIdx.x; idx < items; idx += (int64_t)nblk * NT) {
         const uint32_t pix = fdiv((uint32_t)idx, dq);
         const int hc = ((uint32_t)idx - pix * dq.d) * 4;                 // first hidden channel of the quad
         const int nb = (hc >> 4) * 64 + (hc & 15);
@@ -523,11 +523,19 @@ __global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clea
     }
 }
 
-__global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
-                                   const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32, int dh_b_nslab, int64_t dh_b_slab,
-                                   float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
+__global__ void lstm_fwd_pw_kernel(float* pre, int nslab, int64_t slab, int clear, const float* __restrict__ pre_add,
+                                   const float* __restrict__ bias,
+                                   const float* __restrict__ c_prev, float* __restrict__ c_out, act16* __restrict__ h_out,
+                                   act16* __restrict__ gates_out, int64_t items, FastDiv dq, int Hd_p, int N) {
+    lstm_fwd_pw_body(pre, nslab, slab, clear, pre_add, bias, c_prev, c_out, h_out, gates_out, items, dq, Hd_p, N, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__device__ __forceinline__ void lstm_bwd_pw_body(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                                                 const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32, int dh_b_nslab, int64_t dh_b_slab,
+                                                 float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc,
+                                                 int blk, int nblk) {
     const int cpc = dcpc.d;
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * NT) {
+    for (int64_t idx = (int64_t)blk * NT + threadIdx.x; idx < chunks; idx += (int64_t)nblk * NT) {
         const uint32_t pix = fdiv((uint32_t)idx, dcpc);
         const uint32_t cc = (uint32_t)idx - pix * cpc;
         const int64_t gb = (int64_t)pix * 4 * cpc + cc;
@@ -588,6 +596,34 @@ __global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float*
         dgates[gb + 2 * cpc] = pack8(dg);
         dgates[gb + 3 * cpc] = pack8(dO);
         store8f(dc_io + idx * 8, dc);
+    }
+}
+
+__global__ void lstm_bwd_pw_kernel(const uint4* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                                   const uint4* __restrict__ dh_a, const void* dh_b, int dh_b_is_f32, int dh_b_nslab, int64_t dh_b_slab,
+                                   float* __restrict__ dc_io, int dc_is_zero, uint4* __restrict__ dgates, int64_t chunks, FastDiv dcpc) {
+    lstm_bwd_pw_body(gates, c_prev, c_new, dh_a, dh_b, dh_b_is_f32, dh_b_nslab, dh_b_slab, dc_io, dc_is_zero, dgates, chunks, dcpc, (int)blockIdx.x,
+                     (int)gridDim.x);
+}
+
+// The forward point-wise kernels of several independent ConvLSTMs (one timestep of each) as ONE launch: block ranges per member.
+constexpr int PW_GROUP_MAX = 4;
+struct LstmFwdPwGroup {
+    int n;
+    int first[PW_GROUP_MAX + 1];
+    uclstm_lstm_fwd_pw_args a[PW_GROUP_MAX];
+    FastDiv dq[PW_GROUP_MAX];
+};
+__global__ void lstm_fwd_pw_group_kernel(const LstmFwdPwGroup g) {
+    const int b = (int)blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < PW_GROUP_MAX; ++j) {
+        if (j < g.n && b >= g.first[j] && b < g.first[j + 1]) {
+            const uclstm_lstm_fwd_pw_args& a = g.a[j];
+            lstm_fwd_pw_body(a.pre, a.nslab, a.slab, a.clear, a.pre_add, a.bias, a.c_prev, a.c_out, (act16*)a.h_out, (act16*)a.gates_out,
+                             a.pixels * (a.Hd_p / 4), g.dq[j], a.Hd_p, 64 * ((a.Hd_p + 15) / 16), b - g.first[j], g.first[j + 1] - g.first[j]);
+            return;
+        }
     }
 }
 
@@ -1253,16 +1289,47 @@ extern "C" int32_t uclstm_splitk_finish(const float* pre, int32_t nslab, int64_t
     return UCLSTM_OK;
 }
 
+static bool lstm_fwd_pw_ok(float* pre, int32_t nslab, int64_t slab, const float* pre_add, const float* bias, const float* c_prev, float* c_out,
+                           void* h_out, void* gates_out, int64_t pixels, int32_t Hd_p) {
+    if (!aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return false;
+    if (nslab < 0 || (nslab > 0 && (!pre || !aligned16(pre))) || (nslab == 0 && !pre_add) || (pre_add && !aligned16(pre_add))) return false;
+    if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return false;
+    if (pixels * (Hd_p / 4) >= ((int64_t)1 << 31)) return false;
+    if (nslab > 1 && (slab <= 0 || (slab % 4))) return false;
+    return true;
+}
+static bool lstm_bwd_pw_ok(const void* gates, const float* c_prev, const float* c_new, const void* dh_a, const void* dh_b, int32_t dh_b_is_f32,
+                           int32_t dh_b_nslab, int64_t dh_b_slab, float* dc_io, void* dgates, int64_t pixels, int32_t Hd_p) {
+    if (dh_b && dh_b_is_f32 && (dh_b_nslab < 1 || (dh_b_nslab > 1 && (dh_b_slab <= 0 || (dh_b_slab % 4))))) return false;
+    if (!aligned16(gates) || !aligned16(c_new) || !aligned16(dc_io) || !aligned16(dgates) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return false;
+    if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return false;
+    return pixels * (Hd_p / 8) < ((int64_t)1 << 31);
+}
+
+extern "C" int32_t uclstm_lstm_fwd_pointwise_group(const uclstm_lstm_fwd_pw_args* args, int32_t n, void* stream) {
+    if (!args || n < 1 || n > PW_GROUP_MAX) return UCLSTM_E_BADARG;
+    LstmFwdPwGroup g{};
+    g.n = n;
+    int at = 0;
+    for (int i = 0; i < n; ++i) {
+        const uclstm_lstm_fwd_pw_args& a = args[i];
+        if (!lstm_fwd_pw_ok(a.pre, a.nslab, a.slab, a.pre_add, a.bias, a.c_prev, a.c_out, a.h_out, a.gates_out, a.pixels, a.Hd_p)) return UCLSTM_E_BADARG;
+        g.a[i] = a;
+        g.dq[i] = make_fastdiv(a.Hd_p / 4);
+        g.first[i] = at;
+        at += ew_grid(a.pixels * (a.Hd_p / 4));
+    }
+    for (int i = n; i <= PW_GROUP_MAX; ++i) g.first[i] = at;
+    UCLSTM_LAUNCH(lstm_fwd_pw_group_kernel, dim3(at), dim3(NT), 0, (hipStream_t)stream, g);
+    return UCLSTM_OK;
+}
+
 extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t slab, int32_t clear, const float* pre_add, const float* bias,
                                              const float* c_prev, float* c_out, void* h_out, void* gates_out, int64_t pixels, int32_t Hd_p,
                                              void* stream) {
-    if (!aligned16(c_out) || !aligned16(h_out) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8)) return UCLSTM_E_BADARG;
-    if (nslab < 0 || (nslab > 0 && (!pre || !aligned16(pre))) || (nslab == 0 && !pre_add) || (pre_add && !aligned16(pre_add))) return UCLSTM_E_BADARG;
-    if ((c_prev && !aligned16(c_prev)) || (gates_out && !aligned16(gates_out)) || (bias && !aligned16(bias))) return UCLSTM_E_BADARG;
+    if (!lstm_fwd_pw_ok(pre, nslab, slab, pre_add, bias, c_prev, c_out, h_out, gates_out, pixels, Hd_p)) return UCLSTM_E_BADARG;
     const int64_t items = pixels * (Hd_p / 4);
-    if (items >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     const int N = 64 * ((Hd_p + 15) / 16);
-    if (nslab > 1 && (slab <= 0 || (slab % 4))) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(lstm_fwd_pw_kernel, dim3(ew_grid(items)), dim3(NT), 0, (hipStream_t)stream, pre, nslab, slab, clear, pre_add, bias, c_prev, c_out, (act16*)h_out,
                   (act16*)gates_out, items, make_fastdiv(Hd_p / 4), Hd_p, N);
     return UCLSTM_OK;
@@ -1271,12 +1338,8 @@ extern "C" int32_t uclstm_lstm_fwd_pointwise(float* pre, int32_t nslab, int64_t 
 extern "C" int32_t uclstm_lstm_bwd_pointwise(const void* gates, const float* c_prev, const float* c_new, const void* dh_a,
                                              const void* dh_b, int32_t dh_b_is_f32, int32_t dh_b_nslab, int64_t dh_b_slab, float* dc_io,
                                              int32_t dc_is_zero, void* dgates, int64_t pixels, int32_t Hd_p, void* stream) {
-    if (dh_b && dh_b_is_f32 && (dh_b_nslab < 1 || (dh_b_nslab > 1 && (dh_b_slab <= 0 || (dh_b_slab % 4))))) return UCLSTM_E_BADARG;
-    if (!aligned16(gates) || !aligned16(c_new) || !aligned16(dc_io) || !aligned16(dgates) || pixels <= 0 || Hd_p <= 0 || (Hd_p % 8))
-        return UCLSTM_E_BADARG;
-    if ((c_prev && !aligned16(c_prev)) || (dh_a && !aligned16(dh_a)) || (dh_b && !aligned16(dh_b))) return UCLSTM_E_BADARG;
+    if (!lstm_bwd_pw_ok(gates, c_prev, c_new, dh_a, dh_b, dh_b_is_f32, dh_b_nslab, dh_b_slab, dc_io, dgates, pixels, Hd_p)) return UCLSTM_E_BADARG;
     const int64_t chunks = pixels * (Hd_p / 8);
-    if (chunks >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
     UCLSTM_LAUNCH(lstm_bwd_pw_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)gates, c_prev, c_new,
                        (const uint4*)dh_a, dh_b, dh_b_is_f32, dh_b_nslab, dh_b_slab, dc_io, dc_is_zero, (uint4*)dgates, chunks,
                        make_fastdiv(Hd_p / 8));

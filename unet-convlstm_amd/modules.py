@@ -351,10 +351,27 @@ class TemporalUNetDualView(nn.Module):
                     st.append(None)
                 else:
                     st.append((ops.ToNHWC.apply(s[0].contiguous().float()), ops.StateToNHWC.apply(s[1].contiguous().float())))
-        b_all, new_st = self.temporal.seq_nhwc(seq(xb), st)
+        grouped = False
+        if self.use_skip_lstm and len(self.temporal.layers) == 1:
+            # the three recurrences are independent (train/unet.py:185-191 runs them one after the other): one group launch
+            # per timestep when every member's step GEMM takes the patch shape, else three sequences of launches
+            cells = (self.temporal.layers[0], self.lstm_skip3.layers[0], self.lstm_skip2.layers[0])
+            h0, c0 = (None, None) if (st is None or st[0] is None) else st[0]
+            members = [(seq(xb), h0, c0), (seq(x3), None, None), (seq(x2), None, None)]
+            full = [(xs, hh, cc, cl.conv.weight, cl.conv.bias, cl.hidden_dim, cl.input_dim) for (xs, hh, cc), cl in zip(members, cells)]
+            if ops.convlstm_group_ok(full):
+                needs = [_need_grad(*f[:5]) for f in full]
+                pre = ops.convlstm_group_forward(full, any(needs))
+                outs = [ops.ConvLSTMSeqPre.apply(*f, nd, hh, ch, gt) for f, nd, (hh, ch, gt) in zip(full, needs, pre)]
+                b_all, new_st = outs[0][0], [(outs[0][0][-1], outs[0][1])]
+                x3_l, x2_l = outs[1][0], outs[2][0]
+                grouped = True
+        if not grouped:
+            b_all, new_st = self.temporal.seq_nhwc(seq(xb), st)
+            if self.use_skip_lstm:
+                x3_l, _ = self.lstm_skip3.seq_nhwc(seq(x3), None)
+                x2_l, _ = self.lstm_skip2.seq_nhwc(seq(x2), None)
         if self.use_skip_lstm:
-            x3_l, _ = self.lstm_skip3.seq_nhwc(seq(x3), None)
-            x2_l, _ = self.lstm_skip2.seq_nhwc(seq(x2), None)
             x3 = x3_l.reshape(T * B, *x3_l.shape[2:])
             x2 = x2_l.reshape(T * B, *x2_l.shape[2:])
         b_flat = b_all.reshape(T * B, *b_all.shape[2:])

@@ -790,7 +790,7 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
         if (n_begin, n_end, c_off, sg_scale, oy, ox) == (0, N, 0, 1, 0, 0) and t.is_contiguous() and tuple(t.shape) == (n_img, out_hw[0], out_hw[1], N):
             ksplit = split_k_factor(pixels, N, wp.shape[1] // 64, min_blocks=SPLITK_STORE_BELOW)
             if ksplit > 1:
-                nsl = ksplit_used(wp.shape[1], ksplit)
+                nsl = ksplit_used(wp.shape[1], ksplit, ktap)
                 pre = torch.empty((nsl, pixels, N), dtype=F32, device=t.device)
                 igemm_atomic(srcs, wp, out_hw, n_img, pre, ksplit, ktap=ktap, pad=pad, slabs=True, kind="igemm_fwd_store_splitk")
                 L.check(_k(wp).uclstm_splitk_finish(_p(pre), nsl, pre.stride(0), N, _p(bias), _p(col_scale), _p(col_shift), int(relu), _p(t),
@@ -828,19 +828,18 @@ def split_k_factor(pixels: int, N: int, ksteps: int, min_blocks: int = 384, targ
     return max(1, min((target + tiles - 1) // tiles, ksteps // 8))
 
 
-def ksplit_used(Ktot: int, ksplit: int) -> int:
-    """K ranges the library really uses for a requested split (every range non-empty) = slab count of ``slabs=True``."""
-    n = int(L.lib.uclstm_igemm_ksplit_used(Ktot, ksplit))
+def ksplit_used(Ktot: int, ksplit: int, ktap: int = 3) -> int:
+    """K ranges the library really uses for a requested split (whole chunks of ktap^2 K-steps, every range non-empty) = slab
+    count of ``slabs=True``."""
+    n = int(L.lib.uclstm_igemm_ksplit_used(Ktot, ktap, ksplit))
     if n < 1:
-        raise L.UclstmError(f"igemm_ksplit_used({Ktot}, {ksplit}): bad argument")
+        raise L.UclstmError(f"igemm_ksplit_used({Ktot}, {ktap}, {ksplit}): bad argument")
     return n
 
 
-def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
-                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False, kind: str = "igemm_fwd_atomic") -> None:
-    """Split-K convolution as `ksplit` K ranges.  ``slabs=False``: acc_out[pixel, n] += ... with f32 atomics
-    (acc_out f32 [pixels, ld>=N], zeroed by the caller).  ``slabs=True``: acc_out is [ksplit_used, pixels, ld]; range r
-    stores into acc_out[r] and the consumer adds the slabs (plain stores run ~4.6x faster than float atomics)."""
+def _atomic_desc(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
+                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False):
+    """Descriptor of a split-K launch: (desc, algorithmic flops, algorithmic bytes, note, tensors to keep alive)."""
     _dev(acc_out, F32, "acc_out")
     d = L.IgemmDesc()
     d.n_img, d.H, d.W, d.groups = n_img, out_hw[0], out_hw[1], 1
@@ -851,22 +850,28 @@ def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, i
     d.relu, d.epi, d.nseg = 0, L.EPI_ATOMIC, 0
     d.acc_out, d.acc_ld, d.ksplit = acc_out.data_ptr(), acc_out.shape[-1], ksplit
     d.acc_slab = acc_out.stride(0) if slabs else 0
-    if slabs and (acc_out.dim() != 3 or acc_out.shape[0] != ksplit_used(d.Ktot, ksplit) or not acc_out.is_contiguous()):
+    if slabs and (acc_out.dim() != 3 or acc_out.shape[0] != ksplit_used(d.Ktot, ksplit, ktap) or not acc_out.is_contiguous()):
         raise L.UclstmError("igemm_atomic(slabs=True): acc_out must be a contiguous [ksplit_used, pixels, ld] tensor")
     flops = 2.0 * n_img * out_hw[0] * out_hw[1] * d.N * ktap * ktap * sum(s.t.shape[3] for s in srcs)
-    _log_shape(d)
     _same_act_dtype([sv.t for sv in srcs] + [wp], "igemm_fwd(atomic)")
+    nbytes = _nb(*[sv.t for sv in srcs], wp) + 4.0 * n_img * out_hw[0] * out_hw[1] * d.N if PROFILE is not None else 0.0
+    return d, flops, nbytes, f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}"
+
+
+def igemm_atomic(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, acc_out: torch.Tensor, ksplit: int, *,
+                 ktap: int, scale: int = 1, pad: int = 0, slabs: bool = False, kind: str = "igemm_fwd_atomic") -> None:
+    """Split-K convolution as `ksplit` K ranges.  ``slabs=False``: acc_out[pixel, n] += ... with f32 atomics
+    (acc_out f32 [pixels, ld>=N], zeroed by the caller).  ``slabs=True``: acc_out is [ksplit_used, pixels, ld]; range r
+    stores into acc_out[r] and the consumer adds the slabs (plain stores run ~4.6x faster than float atomics)."""
+    d, flops, nbytes, note = _atomic_desc(srcs, wp, out_hw, n_img, acc_out, ksplit, ktap=ktap, scale=scale, pad=pad, slabs=slabs)
+    _log_shape(d)
     K = _k(wp)
-    _timed(_kernel_kind(kind, d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"),
-           f"M={n_img * out_hw[0] * out_hw[1]} N={d.N} K={d.Ktot} ktap={ktap} ksplit={ksplit}",
-           nbytes=_nb(*[sv.t for sv in srcs], wp) + 4.0 * n_img * out_hw[0] * out_hw[1] * d.N if PROFILE is not None else 0.0)
+    _timed(_kernel_kind(kind, d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(atomic)"), note, nbytes=nbytes)
 
 
-def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
+def _lstm_desc(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
                c_out: torch.Tensor, h_out: torch.Tensor, gates_out: Optional[torch.Tensor], ksize: int = 3,
-               pre_add: Optional[torch.Tensor] = None) -> None:
-    """Fused ConvLSTM cell step.  ``x`` given: gate conv over (x_t, h_{t-1}) with the two-source panel.  ``x=None``: the
-    launch carries W_h * h_{t-1} only and ``pre_add`` (f32 [pixels, N]) holds the hoisted W_x * x_t."""
+               pre_add: Optional[torch.Tensor] = None):
     d = L.IgemmDesc()
     B, H, W, _ = h_prev.shape
     d.n_img, d.H, d.W, d.groups = B, H, W, 1
@@ -887,11 +892,37 @@ def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor
     d.c_out, d.h_out = c_out.data_ptr(), h_out.data_ptr()
     d.gates_out = None if gates_out is None else gates_out.data_ptr()
     flops = 2.0 * B * H * W * (4 * d.Hd_p) * ksize * ksize * ((x.shape[3] if x is not None else 0) + h_prev.shape[3])
-    _log_shape(d)
     _same_act_dtype([h_prev, wp, h_out] + ([x] if x is not None else []) + ([gates_out] if gates_out is not None else []), "igemm_fwd(lstm)")
+    nbytes = _nb(x, h_prev, wp, c_prev, c_out, h_out, gates_out, pre_add) if PROFILE is not None else 0.0
+    return d, flops, nbytes, f"M={B * H * W} N={d.N} K={d.Ktot}"
+
+
+def igemm_lstm(x: Optional[torch.Tensor], h_prev: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_prev: Optional[torch.Tensor],
+               c_out: torch.Tensor, h_out: torch.Tensor, gates_out: Optional[torch.Tensor], ksize: int = 3,
+               pre_add: Optional[torch.Tensor] = None) -> None:
+    """Fused ConvLSTM cell step.  ``x`` given: gate conv over (x_t, h_{t-1}) with the two-source panel.  ``x=None``: the
+    launch carries W_h * h_{t-1} only and ``pre_add`` (f32 [pixels, N]) holds the hoisted W_x * x_t."""
+    d, flops, nbytes, note = _lstm_desc(x, h_prev, wp, bias, c_prev, c_out, h_out, gates_out, ksize, pre_add)
+    _log_shape(d)
     K = _k(wp)
-    _timed(_kernel_kind("igemm_fwd_lstm", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"),
-           f"M={B * H * W} N={d.N} K={d.Ktot}", nbytes=_nb(x, h_prev, wp, c_prev, c_out, h_out, gates_out, pre_add))
+    _timed(_kernel_kind("igemm_fwd_lstm", d), flops, lambda: L.check(K.uclstm_igemm_fwd(C.byref(d), _stream()), "igemm_fwd(lstm)"), note,
+           nbytes=nbytes)
+
+
+def igemm_group(items, K, kind: str = "igemm_fwd_group") -> None:
+    """``items``: [(desc, flops, nbytes, note)] of INDEPENDENT launches -> one uclstm_igemm_fwd_group launch."""
+    arr = (L.IgemmDesc * len(items))(*[it[0] for it in items])
+    for it in items:
+        _log_shape(it[0])
+    _timed(kind + "[patch128x256]" if PROFILE is not None else kind, sum(it[1] for it in items),
+           lambda: L.check(K.uclstm_igemm_fwd_group(arr, len(items), _stream()), "igemm_fwd_group"),
+           " | ".join(it[3] for it in items), nbytes=sum(it[2] for it in items))
+
+
+def group_launchable(descs) -> bool:
+    """True when uclstm_igemm_fwd_group accepts these descriptors as one launch (all on the patch shape, same source count)."""
+    arr = (L.IgemmDesc * len(descs))(*descs)
+    return int(L.lib.uclstm_igemm_fwd_group_blocks(arr, len(descs))) > 0
 
 
 def igemm_wgrad(srcs: Sequence[SrcView], dy_segs, N: int, Ktot: int, out_hw: Tuple[int, int], n_img: int, *, ktap: int, scale: int = 1,
@@ -1542,7 +1573,7 @@ class ConvLSTMSeq(torch.autograd.Function):
             wp = pack_weights(pd, weight, 0, adt)
         ksplit = split_k_factor(pixels, wp.shape[0], wp.shape[1] // 64)
         # one f32 slab per K range (plain stores; the point-wise kernel adds them): no atomics, nothing to zero
-        nsl = ksplit_used(wp.shape[1], ksplit) if ksplit > 1 else 0
+        nsl = ksplit_used(wp.shape[1], ksplit, ks) if ksplit > 1 else 0
         pre = torch.empty((nsl, pixels, wp.shape[0]), dtype=F32, device=dev) if ksplit > 1 else None
         for t in range(T):
             c_prev = (c0 if (direct and t == 0) else c_hist[t]) if (c0 is not None or t > 0) else None
@@ -1592,7 +1623,7 @@ class ConvLSTMSeq(torch.autograd.Function):
         ksplit = split_k_factor(pixels, ddh.N, ddh.Ktot // 64)
         # split-K: one f32 slab per K range, plain stores; the point-wise kernel of the next (earlier) timestep adds them.
         # Two buffers alternate so that step t's GEMM never writes what step t+1's point-wise kernel still reads.
-        nsl = ksplit_used(ddh.Ktot, ksplit) if ksplit > 1 else 1
+        nsl = ksplit_used(ddh.Ktot, ksplit, ks) if ksplit > 1 else 1
         if ksplit > 1:
             buf = [torch.empty((nsl, B, H, W, Hdp), dtype=F32, device=dev) for _ in range(2)]
         else:
@@ -1635,6 +1666,177 @@ class ConvLSTMSeq(torch.autograd.Function):
         dh0 = (dh_rec if dh_rec.dtype == adt else dh_rec.sum(dim=0).to(adt)) if need_h0 else None
         dc0 = dc if (has_c0 and ctx.needs_input_grad[2]) else None
         return dx_all, dh0, dc0, dweight, dbias, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# Several independent ConvLSTMs advancing in lockstep (train/unet.py:185-191 runs temporal, lstm_skip3, lstm_skip2 one after
+# the other; they do not depend on each other)
+# ---------------------------------------------------------------------------------------------
+GROUP_LSTM = os.environ.get("UCLSTM_GROUP_LSTM", "1") != "0"
+_GROUP_PLANS: dict = {}
+_CUS = 256
+_BLOCK_OVERHEAD_STEPS = 12.0          # prologue + epilogue of a patch-shape block in units of one K-step (~10 us / 0.87 us)
+
+
+def _lpt_makespan(blocks: List[Tuple[float, int]], cus: int = _CUS) -> float:
+    """Makespan of (duration, count) block classes handed out longest first to ``cus`` one-block-at-a-time workers."""
+    import heapq
+    free = [0.0] * cus
+    for dur, cnt in sorted(blocks, reverse=True):
+        for _ in range(cnt):
+            t = heapq.heappop(free)
+            heapq.heappush(free, t + dur)
+    return max(free)
+
+
+def plan_group_ksplit(members: Sequence[Tuple[int, int]]) -> Tuple[int, ...]:
+    """K ranges per member of a group launch.  ``members``: (tiles, chunks) = 128 x 256 output tiles and (source, 64-channel)
+    K chunks of each member's GEMM; a block of member i runs ceil(chunks_i / ksplit_i) chunks of 9 K-steps plus a fixed
+    prologue / epilogue.  Exhaustive search over ksplit <= 16 per member for the smallest longest-block-first makespan on the
+    256 CUs (every extra K range also costs an f32 slab round trip, priced at a quarter of a K-step per slab and tile row)."""
+    key = tuple(members)
+    hit = _GROUP_PLANS.get(key)
+    if hit is not None:
+        return hit
+    import itertools
+    options = []
+    for tiles, chunks in members:
+        ks = sorted({k for k in range(1, min(chunks, 16) + 1) if (chunks + k - 1) // k != (chunks + k - 2) // max(k - 1, 1) or k == 1})
+        options.append(ks)
+    best, best_cost = None, None
+    for combo in itertools.product(*options):
+        blocks, slab_cost = [], 0.0
+        for (tiles, chunks), k in zip(members, combo):
+            cper = (chunks + k - 1) // k
+            used = (chunks + cper - 1) // cper
+            full, rem = divmod(chunks, cper)
+            blocks.append((9.0 * cper + _BLOCK_OVERHEAD_STEPS, tiles * full))
+            if rem:
+                blocks.append((9.0 * rem + _BLOCK_OVERHEAD_STEPS, tiles))
+            if used > 1:
+                slab_cost += 0.25 * used * tiles / _CUS * 8
+        cost = _lpt_makespan(blocks) + slab_cost
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = combo, cost
+    _GROUP_PLANS[key] = best
+    return best
+
+
+class _LstmMember:
+    """Per-member state of ConvLSTMGroup (what ConvLSTMSeq keeps in locals)."""
+    pass
+
+
+def convlstm_group_forward(members, need_grad: bool):
+    """All T forward steps of n independent single-layer ConvLSTMs with ONE group launch per timestep (uclstm_igemm_fwd_group)
+    instead of n launches.  ``members``: (x_all [T,B,H,W,Cxp], h0, c0, weight, bias, Hd, Cx) each; returns per member
+    (h_hist [T+1,...], c_hist [T+1,...], gates or None) -- exactly what ConvLSTMSeq.forward keeps -- so that every member gets
+    its OWN autograd node (ConvLSTMSeqPre) and its backward pass runs when ITS gradient arrives, as with separate sequences.
+    (One node for the whole group was measured: backward 21.3 -> 21.8 ms, because the three weight-gradient GEMMs then reach
+    the side stream together at the end instead of each overlapping the next LSTM's backward recurrence.)
+    Same arithmetic as ConvLSTMSeq: a member's step is the fused cell kernel or split-K slabs + the point-wise kernel; only the
+    K-range counts are planned for the group (plan_group_ksplit), i.e. results agree to f32 summation order of the K ranges."""
+    ms = []
+    for x_all, h0, c0, weight, bias, Hd, Cx in members:
+        m = _LstmMember()
+        m.x_all, m.h0, m.c0, m.weight, m.bias, m.Hd, m.Cx = x_all, h0, c0, weight, bias, Hd, Cx
+        _dev(m.x_all, ACT, "x_all")
+        m.T, m.B, m.H, m.W, m.Cxp = m.x_all.shape
+        m.Hdp = cpad(Hd)
+        m.pixels = m.B * m.H * m.W
+        m.pd = lstm_pack_desc(Hd, Cx, 3)
+        m.bp = pack_bias(m.pd, m.bias) if m.bias is not None else None
+        m.wp = pack_weights(m.pd, m.weight, 0, m.x_all.dtype)
+        ms.append(m)
+    T, adt, dev = ms[0].T, ms[0].x_all.dtype, ms[0].x_all.device
+    K = L.kernels(adt)
+    plan = plan_group_ksplit([(((m.wp.shape[0] + 127) // 128) * (m.pixels // 256), m.wp.shape[1] // (64 * 9)) for m in ms])
+    for m, ks in zip(ms, plan):
+        m.h_hist = torch.empty((T + 1, m.B, m.H, m.W, m.Hdp), dtype=adt, device=dev)
+        m.c_hist = torch.empty((T + 1, m.B, m.H, m.W, m.Hdp), dtype=F32, device=dev)
+        if m.h0 is None:
+            m.h_hist[0].zero_()
+        else:
+            m.h_hist[0].copy_(m.h0)
+        if m.c0 is not None:
+            m.c_hist[0].copy_(m.c0)
+        m.gates = torch.empty((T, m.B, m.H, m.W, 4, m.Hdp), dtype=adt, device=dev) if need_grad else None
+        m.ksplit = ks
+        m.nsl = ksplit_used(m.wp.shape[1], ks, 3) if ks > 1 else 0
+        m.pre = torch.empty((m.nsl, m.pixels, m.wp.shape[0]), dtype=F32, device=dev) if ks > 1 else None
+    for t in range(T):
+        items, pws = [], []
+        for m in ms:
+            c_prev = m.c_hist[t] if (m.c0 is not None or t > 0) else None
+            g_t = m.gates[t] if need_grad else None
+            if m.ksplit > 1:
+                items.append(_atomic_desc([SrcView(m.x_all[t]), SrcView(m.h_hist[t])], m.wp, (m.H, m.W), m.B, m.pre, m.ksplit, ktap=3, pad=1,
+                                          slabs=True))
+                a = L.LstmFwdPwArgs()
+                a.pre, a.nslab, a.slab, a.clear, a.pre_add = m.pre.data_ptr(), m.nsl, m.pre.stride(0), 0, None
+                a.bias = None if m.bp is None else m.bp.data_ptr()
+                a.c_prev = None if c_prev is None else c_prev.data_ptr()
+                a.c_out, a.h_out = m.c_hist[t + 1].data_ptr(), m.h_hist[t + 1].data_ptr()
+                a.gates_out = None if g_t is None else g_t.data_ptr()
+                a.pixels, a.Hd_p = m.pixels, m.Hdp
+                pws.append(a)
+            else:
+                items.append(_lstm_desc(m.x_all[t], m.h_hist[t], m.wp, m.bp, c_prev, m.c_hist[t + 1], m.h_hist[t + 1], g_t, 3))
+        igemm_group(items, K)
+        if pws:
+            arr = (L.LstmFwdPwArgs * len(pws))(*pws)
+            L.check(K.uclstm_lstm_fwd_pointwise_group(arr, len(pws), _stream()), "lstm_fwd_pointwise_group")
+    return [(m.h_hist, m.c_hist, m.gates) for m in ms]
+
+
+class ConvLSTMSeqPre(torch.autograd.Function):
+    """ConvLSTMSeq whose forward pass has already been computed (convlstm_group_forward): the node only records what
+    ConvLSTMSeq.forward would have saved; its backward IS ConvLSTMSeq.backward."""
+
+    @staticmethod
+    def forward(ctx, x_all, h0, c0, weight, bias, Hd, Cx, need_grad, h_hist, c_hist, gates):
+        ctx.set_materialize_grads(False)
+        T = x_all.shape[0]
+        if need_grad:
+            ctx.save_for_backward(x_all, weight, h_hist, c_hist, gates, bias)
+            ctx.cfg = (Hd, Cx, c0 is not None, bias is not None, weight.shape[-1])
+            note_use(weight, bias)
+        return h_hist[1:], c_hist[T]
+
+    @staticmethod
+    def backward(ctx, dh_all, dc_T):
+        return ConvLSTMSeq.backward(ctx, dh_all, dc_T) + (None, None, None)
+
+
+def convlstm_group_ok(members) -> bool:
+    """Can these (x_all, h0, c0, weight, bias, Hd, Cx) single-layer ConvLSTMs run as ConvLSTMGroup?  Every per-step GEMM must
+    take the patch shape (3x3 gate convolution, channel counts multiples of 64, B*h*w a multiple of 256, ...) -- checked with the
+    library's own planner on the step-0 descriptors -- and all members share T, B and the activation dtype."""
+    if not GROUP_LSTM or len(members) < 2 or len(members) > 4:
+        return False
+    x0 = members[0][0]
+    try:
+        descs = []
+        for x_all, h0, c0, weight, bias, Hd, Cx in members:
+            if x_all.dim() != 5 or x_all.shape[0] != x0.shape[0] or x_all.shape[1] != x0.shape[1] or x_all.dtype != x0.dtype:
+                return False
+            if weight.shape[-1] != 3 or cpad(Hd) != Hd or Hd % 64 or x_all.shape[4] % 64 or (x_all.shape[1] * x_all.shape[2] * x_all.shape[3]) % 256:
+                return False
+            T, B, H, W, Cxp = x_all.shape
+            pd = lstm_pack_desc(Hd, Cx, 3)
+            # a descriptor with the right shapes (the planner does not dereference the pointers): x_t, h, panel geometry
+            d = L.IgemmDesc()
+            d.n_img, d.H, d.W, d.groups = B, H, W, 1
+            d.ktap, d.scale, d.pad, d.nsrc = 3, 1, 1, 2
+            for i, cch in enumerate((Cxp, Hd)):
+                d.src[i].ptr, d.src[i].C, d.src[i].Hs, d.src[i].Ws = x_all.data_ptr(), cch, H, W
+            d.wp, d.N, d.Ktot = x_all.data_ptr(), pd.N, pd.Ktot
+            d.epi, d.Hd_p = L.EPI_LSTM, Hd
+            d.c_out = d.h_out = x_all.data_ptr()
+            descs.append(d)
+        return group_launchable(descs)
+    except Exception:
+        return False
 
 
 # ---------------------------------------------------------------------------------------------
