@@ -48,6 +48,10 @@ def parse():
                     help="weak (default): per-GPU batch = --batch on every rank; strong: --global-batch sequences in total, "
                          "per-GPU batch = global / N (SURVEY.md 8e: global 32 -> 4 per GPU at N = 8)")
     ap.add_argument("--global-batch", type=int, default=32, help="total sequences per step with --scaling strong")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the training step as ONE captured HIP graph (engine.GraphedTrainStep; single rank only): host enqueue "
+                         "time per step drops from 10-19 ms to < 0.2 ms; the step itself is device-bound at every batch size "
+                         "(DESIGN.md section 6), so the frame rate does not move")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second north_star workload (cloud 128x128 seq-8, same per-GPU batch) that follows the headline")
     ap.add_argument("--seq", type=int, default=20)
@@ -229,7 +233,13 @@ def run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, *, size, se
     data = U.SyntheticSequences(batch, seq, size, size, seed=1 + rank, kind="uniform", device=dev)
     x, y = data.x, data.y
 
+    graphed = None
+    if getattr(a, "graph", False) and ddp is None and opt.capturable:
+        graphed = U.GraphedTrainStep(model, opt, x, y, None, False, warmup=2)
+
     def step():
+        if graphed is not None:
+            return graphed(x, y)
         return U.train_step(model, opt, x, y, None, False, ddp)      # USE_MASK = False, main.py:219
 
     for i in range(warmup):
@@ -407,7 +417,8 @@ def main():
     if a.mode == "rollout":
         return rollout_bench(a, U, dev, skip)
     model = U.TemporalUNetDualView(1, 1, base_ch=a.base_ch, lstm_layers=1, use_skip_lstm=skip, use_attention=False).to(dev).train()
-    opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0, loss_scale=2.0 ** 14 if a.dtype == "f16" else None)
+    opt = U.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0, loss_scale=2.0 ** 14 if a.dtype == "f16" else None,
+                       capturable=bool(a.graph and a.dtype != "f16" and world == 1 and not a.force_ddp))
     ddp = U.FlatDDP(model, opt.flat, grad_dtype=torch.bfloat16 if a.bf16_buckets else None) if (world > 1 or a.force_ddp) else None
     exchange = None
     if ddp is not None:
@@ -456,6 +467,7 @@ def main():
             **({"rehearsal": "all ranks on cuda:0, collectives over gloo -- not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
             "final_loss": round(head["loss"], 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "side_stream": overlap, "host_gc": "collected and frozen after warm-up",
             "step_ms_min_median_max": head["per_step"],
+            **({"hip_graph": "whole training step replayed as one captured HIP graph"} if (a.graph and opt.capturable) else {}),
         }
         for k in ("model_tflops", "model_mfma_frac"):
             if k in head:

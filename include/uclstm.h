@@ -376,6 +376,12 @@ int32_t uclstm_sumsq(const float* g, int64_t n, double* out /* accumulates, call
 int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* uclstm_adamw_step with every hyper-parameter and the step count in DEVICE memory: hyper = f32[8] {lr, beta1, beta2, eps,
+ * weight_decay, max_norm (<= 0: no clipping), optimiser steps done so far, reserved}; the count is incremented on the device
+ * after the update.  Nothing about the launch depends on host state, so it can be captured in a HIP graph and replayed while a
+ * scheduler changes lr between replays (one small host-to-device copy). */
+int32_t uclstm_adamw_step_dev(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float* hyper, void* stream);
+
 /* fp16 training (the _f16 twins below): the backward pass runs on loss * scale so that fp16 activation gradients stay out of
  * the subnormal range, and g holds scale x the true gradient.  scale_state = DEVICE f32[3] {scale, growth tracker, successful
  * steps}.  uclstm_adamw_step_scaled is uclstm_adamw_step on g / scale (clip on the unscaled norm when max_norm > 0, Adam's

@@ -214,3 +214,39 @@ def test_forward_under_no_grad_takes_the_inference_path_and_counts_no_uses():
         assert any(k[0] == "bn_eval" for k in cache.entries if isinstance(k[0], str))
         again = blk(x)
         assert len(cache.entries) == n and torch.equal(again, folded)
+
+
+def test_graphed_train_step_replays_the_eager_step():
+    """engine.GraphedTrainStep: the whole training step (zero_grad -> forward -> loss -> backward on two streams -> clip -> AdamW)
+    captured as ONE HIP graph.  Two models with the same seed: three eager steps against two eager warm-up steps + one replay
+    give the same loss and parameters; a changed learning rate reaches the replay through the device-side hyper-parameters; the
+    optimiser's step count lives on the device."""
+    def make(capturable):
+        torch.manual_seed(5)
+        m = U.TemporalUNetDualView(1, 1, base_ch=16, use_skip_lstm=True).to(DEV).train()
+        o = U.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0, capturable=capturable)
+        return m, o
+    d = U.SyntheticSequences(4, 5, 64, 64, seed=6, kind="uniform")
+    m1, o1 = make(False)
+    m2, o2 = make(True)
+    for _ in range(3):
+        l1, _ = U.train_step(m1, o1, d.x, d.y, d.mask, True)
+    g = U.GraphedTrainStep(m2, o2, d.x, d.y, d.mask, True, warmup=2)
+    assert int(o2.hyper[6]) == 2                      # the capture itself executes nothing
+    l2, yp = g(d.x, d.y, d.mask)
+    torch.cuda.synchronize()
+    e_p = rel_l2(o2.flat.flat_p.cpu(), o1.flat.flat_p.cpu())
+    print(f"[parity] graph replay vs eager, step 3: loss {float(l2):.7f} / {float(l1):.7f}, parameters rel-L2 {e_p:.2e}")
+    assert abs(float(l2) - float(l1)) <= 1e-6 * abs(float(l1)) and e_p <= 1e-6 and int(o2.hyper[6]) == 3 and yp.shape[1] == 5
+    # new data + new learning rate through the static buffers / the device-side hyper-parameters
+    d2 = U.SyntheticSequences(4, 5, 64, 64, seed=7, kind="uniform")
+    for o in (o1, o2):
+        o.param_groups[0]["lr"] = 5e-4
+    l1, _ = U.train_step(m1, o1, d2.x, d2.y, d2.mask, True)
+    l2, _ = g(d2.x, d2.y, d2.mask)
+    torch.cuda.synchronize()
+    e_p = rel_l2(o2.flat.flat_p.cpu(), o1.flat.flat_p.cpu())
+    print(f"[parity] graph replay vs eager, step 4 (new batch, lr 5e-4): loss {float(l2):.7f} / {float(l1):.7f}, parameters rel-L2 {e_p:.2e}")
+    assert abs(float(l2) - float(l1)) <= 1e-5 * abs(float(l1)) and e_p <= 1e-5
+    sd = o2.state_dict()
+    assert sd["fused"]["step"] == 4

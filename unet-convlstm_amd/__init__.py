@@ -14,12 +14,12 @@ from .modules import (ConvLSTMCell, ConvLSTM, DoubleConv, Down, Up, OutConv, Spa
                       TemporalUNetDualView, UNet)
 from .loss import compute_loss
 from .optim import FusedAdamW
-from .engine import train_one_epoch, evaluate, train_step, quiesce_host_gc, SyntheticSequences, NPZSequenceDataset, device_transform
+from .engine import train_one_epoch, evaluate, train_step, GraphedTrainStep, quiesce_host_gc, SyntheticSequences, NPZSequenceDataset, device_transform
 from .ddp import FlatDDP
 from .streaming import StreamingPredictor
 from .ops import compute_dtype, set_compute_dtype, get_compute_dtype
 
 __all__ = ["ConvLSTMCell", "ConvLSTM", "DoubleConv", "Down", "Up", "OutConv", "SpatialAttention",
            "TemporalUNetDualView", "UNet", "compute_loss", "FusedAdamW", "train_one_epoch", "evaluate",
-           "train_step", "quiesce_host_gc", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "StreamingPredictor", "UclstmError", "ops",
+           "train_step", "GraphedTrainStep", "quiesce_host_gc", "SyntheticSequences", "NPZSequenceDataset", "device_transform", "FlatDDP", "StreamingPredictor", "UclstmError", "ops",
            "compute_dtype", "set_compute_dtype", "get_compute_dtype"]

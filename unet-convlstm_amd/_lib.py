@@ -135,6 +135,7 @@ _PROTOS = {
     "uclstm_loss_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "uclstm_sumsq": [_P, _L, _P, _P],
     "uclstm_adamw_step": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _P],
+    "uclstm_adamw_step_dev": [_P, _P, _P, _P, _L, _P, _P, _P],
     "uclstm_adamw_step_scaled": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P],
     "uclstm_loss_scale_update": [_P, _P, _F, _F, _I, _P],
     "uclstm_dataset_transform": [_P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _I, _F, _F, _F, _P],

@@ -132,6 +132,36 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
     }
 }
 
+// The same update with every hyper-parameter and the step count read from DEVICE memory, so that the launch can sit in a
+// captured HIP graph and still follow a learning-rate schedule: hyper = {lr, beta1, beta2, eps, weight_decay, max_norm
+// (<= 0: no clipping), steps done so far (float, exact up to 2^24), reserved}.  adamw_advance_kernel bumps the count afterwards.
+__global__ void adamw_dev_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                                 int64_t n, const double* __restrict__ sumsq, const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], max_norm = hyper[5];
+    const double step = (double)hyper[6] + 1.0;
+    const float inv_bc1 = (float)(1.0 / (1.0 - pow((double)b1, step)));          // as the host computes them for adamw_kernel
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, step)));
+    float coef = 1.f;
+    if (sumsq && max_norm > 0.f) {
+        const float total = (float)sqrt(*sumsq);
+        coef = fminf(max_norm / (total + 1e-6f), 1.f);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gi = g[i] * coef;
+        float w = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        w -= lr * inv_bc1 * mi / denom;
+        p[i] = w;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+__global__ void adamw_advance_kernel(float* hyper) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) hyper[6] += 1.f;
+}
+
 // fp16 training: the gradient buffer holds scale x the true gradient (loss scaling keeps fp16 activation gradients out of the
 // subnormal range).  state = {scale, growth tracker, successful steps}.  Same update as adamw_kernel on g / scale; nothing is
 // touched when the scaled sum of squares is not finite (an overflowed step is skipped, the scale backs off in
@@ -261,6 +291,14 @@ extern "C" int32_t uclstm_adamw_step(float* p, float* m, float* v, const float* 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     UCLSTM_LAUNCH(adamw_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_adamw_step_dev(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float* hyper,
+                                         void* stream) {
+    if (!p || !m || !v || !g || n <= 0 || !hyper || ((uintptr_t)hyper % 16)) return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(adamw_dev_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)stream, p, m, v, g, n, sumsq, (const float*)hyper);
+    UCLSTM_LAUNCH(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper);
     return UCLSTM_OK;
 }
 

@@ -203,6 +203,58 @@ def train_step(model, optimizer, x, y, mask=None, use_mask=True, ddp=None, clip_
     return loss.detach(), y_pred.detach()
 
 
+class GraphedTrainStep:
+    """``train_step`` captured ONCE as a HIP graph and replayed: a training step is ~400 kernel launches issued from Python
+    through ctypes (12-19 ms of host time); at the per-GPU batch the benchmark uses the device needs longer than that, but at
+    small batches (strong scaling: a global batch of 32 over 8 GPUs is 4 sequences each) the step is bound by the host.  A
+    replay costs the host one call.
+
+    What makes the step capturable: no host synchronisation anywhere in it; the optimiser reads its hyper-parameters and step
+    count from device memory (``FusedAdamW(capturable=True)``); the weight-gradient / BatchNorm side stream forks from and joins
+    the capturing stream through events; the look-ahead panel packing uses a persistent job table.  Inputs are copied into
+    static buffers; ``loss`` / ``y_pred`` are static outputs (valid until the next call).  Shapes, ``use_mask`` and the model's
+    mode are fixed at capture; ``clip_norm`` / lr changes reach the device through ``optimizer.sync_hyper()`` before a replay.
+    Data-parallel training keeps the eager step (its collectives are launched from backward hooks)."""
+
+    def __init__(self, model, optimizer, x, y, mask=None, use_mask: bool = True, clip_norm: Optional[float] = 1.0, warmup: int = 3):
+        if not (isinstance(optimizer, FusedAdamW) and optimizer.capturable):
+            raise ValueError("GraphedTrainStep needs FusedAdamW(..., capturable=True)")
+        if not x.is_cuda:
+            raise ops.L.UclstmError("GraphedTrainStep: HIP device tensors required")
+        self.model, self.optimizer, self.use_mask, self.clip_norm = model, optimizer, use_mask, clip_norm
+        self.x, self.y = x.clone(), y.clone()
+        self.mask = None if mask is None else mask.clone()
+        optimizer.max_grad_norm = clip_norm
+        optimizer.sync_hyper()
+        # eager warm-up steps on a side stream (the capture runs on one too): the look-ahead packing plan, the stream pair,
+        # the caching allocator's pools and every first-launch attribute call exist before the capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(warmup, 2)):
+                train_step(model, optimizer, self.x, self.y, self.mask, use_mask, None, clip_norm)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.y_pred = train_step(model, optimizer, self.x, self.y, self.mask, use_mask, None, clip_norm)
+        self.replays = 0
+
+    def __call__(self, x, y, mask=None):
+        if x is not self.x:
+            self.x.copy_(x, non_blocking=True)
+        if y is not self.y:
+            self.y.copy_(y, non_blocking=True)
+        if self.mask is not None and mask is not None and mask is not self.mask:
+            self.mask.copy_(mask, non_blocking=True)
+        self.optimizer.max_grad_norm = self.clip_norm
+        self.optimizer.sync_hyper()
+        self.graph.replay()
+        self.replays += 1
+        ops.weights_changed()          # what optimizer.step() tells the panel caches in an eager step
+        return self.loss, self.y_pred
+
+
 class _Metrics:
     """Running sums of |d|, d^2, d and the count on the device (replaces main.py:114-142)."""
 

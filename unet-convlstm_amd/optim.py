@@ -56,7 +56,8 @@ class FusedAdamW(torch.optim.Optimizer):
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm: Optional[float] = None,
-                 loss_scale: Optional[float] = None, scale_growth: float = 2.0, scale_backoff: float = 0.5, scale_interval: int = 2000):
+                 loss_scale: Optional[float] = None, scale_growth: float = 2.0, scale_backoff: float = 0.5, scale_interval: int = 2000,
+                 capturable: bool = False):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
@@ -75,6 +76,34 @@ class FusedAdamW(torch.optim.Optimizer):
         self._scale_cfg = (float(scale_growth), float(scale_backoff), int(scale_interval))
         if loss_scale is not None:
             self.scale_state = torch.tensor([float(loss_scale), 0.0, 0.0], dtype=torch.float32, device=self.flat.flat_p.device)
+        # capturable: hyper-parameters and the step count live on the device (uclstm_adamw_step_dev), so that step() makes the
+        # same launches with the same arguments every time and can be captured in a HIP graph (engine.GraphedTrainStep); a
+        # changed lr / max_grad_norm reaches the device through one small copy in sync_hyper(), outside the graph.
+        self.capturable = bool(capturable)
+        self.hyper = None
+        if self.capturable:
+            if loss_scale is not None:
+                raise ValueError("FusedAdamW(capturable=True) does not combine with loss scaling yet")
+            self.hyper = torch.zeros(8, dtype=torch.float32, device=self.flat.flat_p.device)
+            self._hyper_host = None
+            self.sync_hyper()
+
+    def _hyper_values(self):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(self.max_grad_norm or 0.0))
+
+    def sync_hyper(self) -> None:
+        """Push lr / betas / eps / weight_decay / max_grad_norm to the device if they changed (capturable mode; never inside a
+        capture).  The device-side step count is left alone."""
+        if not self.capturable:
+            return
+        vals = self._hyper_values()
+        if vals != self._hyper_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdamW.sync_hyper() inside a graph capture: hyper-parameters must be synchronised before")
+            self.hyper[:6].copy_(torch.tensor(vals, dtype=torch.float32))
+            self._hyper_host = vals
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 - signature parity with torch
         self.flat.zero_grad()
@@ -83,6 +112,8 @@ class FusedAdamW(torch.optim.Optimizer):
     # otherwise a save / load / resume would silently restart Adam.
     def state_dict(self):
         sd = super().state_dict()
+        if self.capturable:
+            self.step_count = int(self.hyper[6].item())          # the device-side count is the truth in capturable mode
         sd["fused"] = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "step": int(self.step_count),
                        "numel": int(self.flat.numel),
                        "scale_state": None if self.scale_state is None else self.scale_state.detach().clone()}
@@ -98,6 +129,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self.m.copy_(fused["exp_avg"])
         self.v.copy_(fused["exp_avg_sq"])
         self.step_count = int(fused["step"])
+        if self.capturable:
+            self.hyper[6] = float(self.step_count)
         if fused.get("scale_state") is not None and self.scale_state is not None:
             self.scale_state.copy_(fused["scale_state"])
 
@@ -132,6 +165,17 @@ class FusedAdamW(torch.optim.Optimizer):
             gr, bo, it = self._scale_cfg
             L.check(L.lib.uclstm_loss_scale_update(C.c_void_p(self.scale_state.data_ptr()), C.c_void_p(self.sumsq.data_ptr()), gr, bo, it,
                                                    _stream()), "loss_scale_update")
+            from . import ops
+            ops.weights_changed()
+            return None
+        if self.capturable:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()
+            self.sumsq.zero_()
+            L.check(L.lib.uclstm_sumsq(C.c_void_p(f.flat_g.data_ptr()), f.numel, C.c_void_p(self.sumsq.data_ptr()), _stream()), "sumsq")
+            L.check(L.lib.uclstm_adamw_step_dev(C.c_void_p(f.flat_p.data_ptr()), C.c_void_p(self.m.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                                C.c_void_p(f.flat_g.data_ptr()), f.numel, C.c_void_p(self.sumsq.data_ptr()),
+                                                C.c_void_p(self.hyper.data_ptr()), _stream()), "adamw_step_dev")
             from . import ops
             ops.weights_changed()
             return None
