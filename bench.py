@@ -288,7 +288,7 @@ def run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, *, size, se
         async_was, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
         ops.PROFILE = [] if rank == 0 else None
         ops.PROFILE_HBM = [] if rank == 0 else None
-        step()
+        U.train_step(model, opt, x, y, None, False, ddp)          # always eager: a graph replay records no per-launch events
         torch.cuda.synchronize()
         ops.ASYNC_WGRAD = async_was
     if roofline and rank == 0:
