@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0              # HBM3E, same guide
-TRAFFIC_FILE = "round2_hbm_traffic.json"
+TRAFFIC_FILE = "round3_hbm_traffic.json"
 TRAFFIC_NOTE = (f"committed PMC passes (profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of "
                 "this command, gfx950 correction applied); NOT measured in this run")
 TRAIN_GFLOP_PER_FRAME = {(64, True, 64): 39.79, (32, False, 64): 6.33, (64, True, 128): 159.17, (32, False, 128): 25.33,

@@ -18,6 +18,8 @@ def family(name: str) -> str:
     if m:          # same keys as bench.py's roofline leg: epilogue family[tile shape]
         epi = {"0": "igemm_fwd_store", "1": "igemm_fwd_lstm", "2": "igemm_fwd_atomic"}[m.group(1)]
         return epi + "[" + {"0": "pertap128x128", "1": "pertap64x256", "2": "patch128x256"}[m.group(2)] + "]"
+    if "igemm_fwd_group_kernel" in name:   # several independent patch-shape GEMMs in one launch (forward recurrence)
+        return "igemm_fwd_group[patch128x256]"
     if "igemm_fwd_c64" in name:        # the persistent 64-channel kernel serves UCLSTM_EPI_STORE launches
         return "igemm_fwd_store[ring64]"
     if "igemm_wgrad_c64" in name:
