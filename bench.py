@@ -140,7 +140,7 @@ def dry_launch(a, world: int, rank: int) -> None:
     else:
         seen = [{"rank": 0, "world_size": 1, "local_rank": 0, "per_gpu_batch": a.batch}]
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": a.gpus, "scaling": a.scaling, "global_batch": a.batch * world, "ranks": seen}), flush=True)
+        emit({"dry_launch": True, "n_gpus": a.gpus, "scaling": a.scaling, "global_batch": a.batch * world, "ranks": seen})
 
 
 def cpu_baseline(base_ch: int, skip: bool, size: int, seq: int):
@@ -223,7 +223,7 @@ def rollout_bench(a, U, dev, skip):
             tot += t_ms
             log(f"{kind:32s} {t_ms * 1e3:8.1f} us {flops / t_ms / 1e9:7.1f} TF/s  {note}")
         log(f"GEMM launches of one frame: {tot * 1e3:.1f} us")
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, *, size, seq, batch, steps, warmup, roofline, tag):
@@ -370,6 +370,25 @@ def run_workload(a, U, ops, dist, dev, world, rank, model, opt, ddp, *, size, se
     return res
 
 
+_JSON_OUT = None          # the process's real stdout, kept for the ONE JSON line (see quiet_stdout)
+
+
+def quiet_stdout() -> None:
+    """Route file descriptor 1 to stderr for the rest of the process and keep the real stdout for the JSON line only: libraries
+    print to stdout on their own (RCCL writes a five-line version banner when the first communicator is created), and the
+    contract is ONE JSON line on stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj) -> None:
+    out = _JSON_OUT or sys.stdout
+    print(json.dumps(obj), file=out, flush=True)
+
+
 def main():
     global torch
     a = parse()
@@ -380,6 +399,7 @@ def main():
         raise SystemExit(self_launch(a))             # this process has not even imported torch
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    quiet_stdout()
     if a.scaling == "strong":
         if a.global_batch % world:
             raise SystemExit(f"--scaling strong: --global-batch {a.global_batch} is not a multiple of {world} ranks")
@@ -478,7 +498,7 @@ def main():
             out["secondary"] = second
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.base_ch, skip, a.size, a.seq)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1 or a.force_ddp:
         dist.destroy_process_group()
 
