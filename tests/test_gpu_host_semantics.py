@@ -262,3 +262,32 @@ def test_graphed_train_step_replays_the_eager_step():
     # the learning rate really took effect: the update is half as long as an lr 1e-3 step from the same state would be
     sd = o2.state_dict()
     assert sd["fused"]["step"] == 4
+
+
+@pytest.mark.parametrize("skip_hw", [(9, 9), (8, 11), (13, 12)])
+def test_up_with_a_skip_smaller_or_larger_than_the_upsampled_map(skip_hw):
+    """train/unet.py:95-97: F.pad with the size difference -- positive pads, NEGATIVE crops (Python floor division decides which
+    side loses the odd pixel).  Round 2 raised on a negative difference; stand-alone Up calls may have one."""
+    torch.manual_seed(31)
+    up = U.Up(16, 8).to(DEV).train()
+    x1 = torch.randn(2, 16, 5, 5)                       # upsampled to 10 x 10
+    x2 = torch.randn(2, 8, *skip_hw)
+    sd = {"up." + k: v.detach().cpu() for k, v in up.state_dict().items()}
+    x1d, x2d = x1.to(DEV).requires_grad_(True), x2.to(DEV).requires_grad_(True)
+    y = up(x1d, x2d)
+    (y * y).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    with O.bf16_storage():
+        yr = O.up(x1r, x2r, {**sd, **leaves}, "up", True, {})
+    (yr * yr).sum().backward()
+    e = rel_l2(y.detach().cpu(), yr.detach())
+    e1, e2 = rel_l2(x1d.grad.cpu(), x1r.grad), rel_l2(x2d.grad.cpu(), x2r.grad)
+    print(f"[parity] Up with skip {skip_hw} vs upsampled 10x10: y {e:.2e}, dx1 {e1:.4f}, dx2 {e2:.4f}")
+    assert tuple(y.shape) == (2, 8, *skip_hw) and e <= 2e-3 and e1 <= 3e-2 and e2 <= 3e-2
+    for k, p in up.named_parameters():
+        r = leaves["up." + k].grad
+        if k in ("conv.net.0.bias", "conv.net.3.bias"):          # conv bias in front of BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) < 1e-3
+            continue
+        assert rel_l2(p.grad.cpu(), r) <= 3e-2, k

@@ -214,9 +214,16 @@ class Up(nn.Module):
         u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
         diffY = x2.shape[1] - u.shape[1]
         diffX = x2.shape[2] - u.shape[2]
+        # cat order is skip first (train/unet.py:98); a non-negative pad is folded into the source view offsets.  A NEGATIVE
+        # difference (the upsampled map is larger than the skip: cannot happen inside the model, floor pooling only shrinks) is
+        # F.pad's crop (train/unet.py:95-97; Python's floor division decides which side loses the odd pixel): the overhang is cut
+        # off here with a slice copy -- the GEMM kernels place sources INSIDE the output frame only.
         if diffY < 0 or diffX < 0:
-            raise UclstmError("Up: the upsampled map is larger than the skip map (negative F.pad is not supported)")
-        # cat order is skip first (train/unet.py:98); the pad is folded into the source view offsets
+            t, l = max(-(diffY // 2), 0), max(-(diffX // 2), 0)
+            hh = min(u.shape[1] - t, x2.shape[1]) if diffY < 0 else u.shape[1]
+            ww = min(u.shape[2] - l, x2.shape[2]) if diffX < 0 else u.shape[2]
+            u = u[:, t:t + hh, l:l + ww, :].contiguous()
+            diffY, diffX = max(diffY, 0), max(diffX, 0)
         return self.conv.forward_nhwc(x2, u, (skip_ch, self.up.out_channels), (diffY // 2, diffX // 2), groups)
 
     def forward(self, x1, x2):

@@ -167,6 +167,10 @@ class SrcView:
     def __init__(self, t: torch.Tensor, offY: int = 0, offX: int = 0):
         _dev(t, ACT, "conv source")
         assert t.dim() == 4 and t.shape[3] % 8 == 0
+        if offY < 0 or offX < 0:
+            # measured: a source that overhangs the output frame reads out of range in the input-gradient / weight-gradient
+            # kernels (garbage, not zeros).  modules.Up crops such a source before it gets here.
+            raise L.UclstmError("conv source offsets must be >= 0 (a source is placed INSIDE the output frame)")
         self.t, self.offY, self.offX = t, offY, offX
 
     def fill(self, s: L.Src):
