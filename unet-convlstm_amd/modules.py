@@ -411,13 +411,27 @@ class TemporalUNetDualView(nn.Module):
         st = full_state or {}
         ost = out_state or {}
         xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
-        b_all, st_t = self.temporal.seq_nhwc(xb.unsqueeze(0), st.get("temporal"), ost.get("temporal"))
-        new_state = {"temporal": st_t}
-        if self.use_skip_lstm:
-            x3_l, st3 = self.lstm_skip3.seq_nhwc(x3.unsqueeze(0), st.get("skip3"), ost.get("skip3"))
-            x2_l, st2 = self.lstm_skip2.seq_nhwc(x2.unsqueeze(0), st.get("skip2"), ost.get("skip2"))
-            x3, x2 = x3_l[0], x2_l[0]
-            new_state["skip3"], new_state["skip2"] = st3, st2
+        grouped = False
+        if (self.use_skip_lstm and len(self.temporal.layers) == 1 and not torch.is_grad_enabled()
+                and all(st.get(k) is not None and ost.get(k) is not None for k in ("temporal", "skip3", "skip2"))):
+            # streaming inference with every state carried and caller-owned output buffers: the three cell steps as ONE launch
+            cells = (self.temporal.layers[0], self.lstm_skip3.layers[0], self.lstm_skip2.layers[0])
+            names, xs = ("temporal", "skip3", "skip2"), (xb, x3, x2)
+            members = [(xx, st[k][0][0], st[k][0][1], ost[k][0][0], ost[k][0][1], cl.conv.weight, cl.conv.bias, cl.hidden_dim, cl.input_dim)
+                       for k, xx, cl in zip(names, xs, cells)]
+            if ops.convlstm_group_step(members):
+                grouped = True
+                b_all = ost["temporal"][0][0].unsqueeze(0)
+                x3, x2 = ost["skip3"][0][0], ost["skip2"][0][0]
+                new_state = {k: [(ost[k][0][0], ost[k][0][1])] for k in names}
+        if not grouped:
+            b_all, st_t = self.temporal.seq_nhwc(xb.unsqueeze(0), st.get("temporal"), ost.get("temporal"))
+            new_state = {"temporal": st_t}
+            if self.use_skip_lstm:
+                x3_l, st3 = self.lstm_skip3.seq_nhwc(x3.unsqueeze(0), st.get("skip3"), ost.get("skip3"))
+                x2_l, st2 = self.lstm_skip2.seq_nhwc(x2.unsqueeze(0), st.get("skip2"), ost.get("skip2"))
+                x3, x2 = x3_l[0], x2_l[0]
+                new_state["skip3"], new_state["skip2"] = st3, st2
         d3 = self.up3.forward_nhwc(b_all[0], x3, c * 8, 1)
         d2 = self.up2.forward_nhwc(d3, x2, c * 4, 1)
         d1 = self.up1.forward_nhwc(d2, x1, c * 2, 1)

@@ -1793,6 +1793,53 @@ def convlstm_group_forward(members, need_grad: bool):
     return [(m.h_hist, m.c_hist, m.gates) for m in ms]
 
 
+def convlstm_group_step(members) -> bool:
+    """ONE inference step of n independent single-layer ConvLSTMs with carried state as one group launch (streaming rollout,
+    BASELINE configs[4]).  ``members``: (x_t [B,H,W,Cxp], h_prev, c_prev, h_out, c_out, weight, bias, Hd, Cx); the new state is
+    written into h_out / c_out (h_out must not alias h_prev; c_out may be c_prev).  Returns False -- nothing launched -- when the
+    members cannot form a group (the caller then steps them one by one)."""
+    if not GROUP_LSTM or not 2 <= len(members) <= 4:
+        return False
+    ms = []
+    for x_t, h_prev, c_prev, h_out, c_out, weight, bias, Hd, Cx in members:
+        if (weight.shape[-1] != 3 or cpad(Hd) != Hd or Hd % 64 or x_t.shape[3] % 64 or (x_t.shape[0] * x_t.shape[1] * x_t.shape[2]) % 256
+                or h_prev is None or c_prev is None or h_out.data_ptr() == h_prev.data_ptr() or x_t.dtype != members[0][0].dtype):
+            return False
+        m = _LstmMember()
+        m.x_t, m.h_prev, m.c_prev, m.h_out, m.c_out, m.Hd = x_t, h_prev, c_prev, h_out, c_out, Hd
+        m.B, m.H, m.W, _ = x_t.shape
+        m.pixels = m.B * m.H * m.W
+        m.pd = lstm_pack_desc(Hd, Cx, 3)
+        m.bp = pack_bias(m.pd, bias) if bias is not None else None
+        m.wp = pack_weights(m.pd, weight, 0, x_t.dtype)
+        ms.append(m)
+    adt, dev = ms[0].x_t.dtype, ms[0].x_t.device
+    K = L.kernels(adt)
+    plan = plan_group_ksplit([(((m.wp.shape[0] + 127) // 128) * (m.pixels // 256), m.wp.shape[1] // (64 * 9)) for m in ms])
+    items, pws, keep = [], [], []
+    for m, ks in zip(ms, plan):
+        if ks > 1:
+            nsl = ksplit_used(m.wp.shape[1], ks, 3)
+            pre = torch.empty((nsl, m.pixels, m.wp.shape[0]), dtype=F32, device=dev)
+            keep.append(pre)
+            items.append(_atomic_desc([SrcView(m.x_t), SrcView(m.h_prev)], m.wp, (m.H, m.W), m.B, pre, ks, ktap=3, pad=1, slabs=True))
+            a = L.LstmFwdPwArgs()
+            a.pre, a.nslab, a.slab, a.clear, a.pre_add = pre.data_ptr(), nsl, pre.stride(0), 0, None
+            a.bias = None if m.bp is None else m.bp.data_ptr()
+            a.c_prev, a.c_out, a.h_out, a.gates_out = m.c_prev.data_ptr(), m.c_out.data_ptr(), m.h_out.data_ptr(), None
+            a.pixels, a.Hd_p = m.pixels, m.Hd
+            pws.append(a)
+        else:
+            items.append(_lstm_desc(m.x_t, m.h_prev, m.wp, m.bp, m.c_prev, m.c_out, m.h_out, None, 3))
+    if not group_launchable([it[0] for it in items]):
+        return False
+    igemm_group(items, K)
+    if pws:
+        arr = (L.LstmFwdPwArgs * len(pws))(*pws)
+        L.check(K.uclstm_lstm_fwd_pointwise_group(arr, len(pws), _stream()), "lstm_fwd_pointwise_group")
+    return True
+
+
 class ConvLSTMSeqPre(torch.autograd.Function):
     """ConvLSTMSeq whose forward pass has already been computed (convlstm_group_forward): the node only records what
     ConvLSTMSeq.forward would have saved; its backward IS ConvLSTMSeq.backward."""
