@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 13
+#define UCLSTM_ABI_VERSION 14
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -256,6 +256,22 @@ int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, c
                             const float* mean, const float* rstd, const float* sums, void* dz,
                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
 
+/* The model's output head fused into its last BatchNorm stage (up0's second conv -> BatchNorm -> ReLU -> OutConv 1x1 with ONE
+ * output channel; train/unet.py:70-71, :101-107, :196-199).  That activation feeds only the output convolution: unfused, a training
+ * step makes six passes over the largest tensor of the model for it and its gradient; fused, neither exists in memory.
+ *   forward:   y[p] = b + sum_c w[c] * bf16(relu(z[p][c]*scale[g][c] + shift[g][c]))            (y f32 [pixels] = NCHW with C = 1)
+ *   backward:  da[p][c] = bf16(dy[p] * w[c]) computed on the fly inside the BatchNorm backward reduction / apply (same partials /
+ *              sums / dz contract as uclstm_bn_bwd_reduce / _apply); dw[c] += sum_p dy[p] * a[p][c], db += sum_p dy[p].
+ * Cp / 8 must be a power of two <= 64; `partials` has uclstm_bn_bwd_reduce_rows() rows. */
+int32_t uclstm_bn_head_fwd(const void* z, const float* scale, const float* shift, const float* w, const float* b, float* y,
+                           int64_t pixels, int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream);
+int32_t uclstm_bn_head_bwd_reduce(const void* z, const float* dy, const float* scale, const float* shift, const float* mean,
+                                  const float* rstd, const float* w, float* partials, float* sums, float* dw, float* db,
+                                  int64_t pixels, int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream);
+int32_t uclstm_bn_head_bwd_apply(const void* z, const float* dy, const float* scale, const float* shift, const float* mean,
+                                 const float* rstd, const float* sums, const float* w, void* dz, int64_t pixels,
+                                 int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream);
+
 /* Parameter gradients of the BatchNorm (train/unet.py:70) from the sums of pass 1, summed over the groups in order:
  * dbeta[c] = (accumulate ? dbeta[c] : 0) + sum_g sums[g][c][0],  dgamma likewise from sums[g][c][1],  c < C. */
 int32_t uclstm_bn_bwd_param_grads(const float* sums, int32_t groups, int32_t Cp, int32_t C, float* dgamma, float* dbeta,
@@ -433,6 +449,9 @@ UCLSTM_F16_TWIN(uclstm_pack_weights_batched)
 UCLSTM_F16_TWIN(uclstm_bn_apply_relu)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_reduce)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_apply)
+UCLSTM_F16_TWIN(uclstm_bn_head_fwd)
+UCLSTM_F16_TWIN(uclstm_bn_head_bwd_reduce)
+UCLSTM_F16_TWIN(uclstm_bn_head_bwd_apply)
 UCLSTM_F16_TWIN(uclstm_maxpool2_fwd)
 UCLSTM_F16_TWIN(uclstm_maxpool2_bwd)
 UCLSTM_F16_TWIN(uclstm_lstm_bwd_pointwise)

@@ -18,6 +18,9 @@
 #define uclstm_bn_apply_relu uclstm_bn_apply_relu_f16
 #define uclstm_bn_bwd_reduce uclstm_bn_bwd_reduce_f16
 #define uclstm_bn_bwd_apply uclstm_bn_bwd_apply_f16
+#define uclstm_bn_head_fwd uclstm_bn_head_fwd_f16
+#define uclstm_bn_head_bwd_reduce uclstm_bn_head_bwd_reduce_f16
+#define uclstm_bn_head_bwd_apply uclstm_bn_head_bwd_apply_f16
 #define uclstm_maxpool2_fwd uclstm_maxpool2_fwd_f16
 #define uclstm_maxpool2_bwd uclstm_maxpool2_bwd_f16
 #define uclstm_lstm_bwd_pointwise uclstm_lstm_bwd_pointwise_f16

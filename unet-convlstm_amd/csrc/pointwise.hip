@@ -471,6 +471,202 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Output head fused into the last BatchNorm stage (train/unet.py:70-71 of up0's second conv + OutConv, :101-107, Co = 1)
+// ---------------------------------------------------------------------------------------------
+// The activation of the last DoubleConv stage feeds ONLY the 1x1 output convolution.  Unfused, a training step writes it
+// (bn_apply_relu), reads it twice (outconv forward, outconv weight gradient), and writes + reads twice its gradient (outconv
+// input gradient -> BatchNorm backward reduce / apply): six passes over the largest tensor of the model.  Fused, the activation
+// and its gradient never exist in memory: forward  y[p] = b + sum_c w[c] * act16(relu(z[p][c]*scale + shift)),  backward works
+// from z and the one-channel dy: da[p][c] = act16(dy[p] * w[c]) exactly as outconv_bwd_da would have stored it.
+// Thread = one 16-byte channel chunk column of `rows` interleaved pixel rows; constants in registers; the cpc lanes of a pixel
+// are adjacent (cpc a power of two <= 64).
+__global__ void bn_head_fwd_kernel(const uint4* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y, int64_t ppg, int Cp,
+                                   int C, ColGeom cg, int blocks_per_group, int64_t pix_per_block) {
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
+    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    const bool act = (int)threadIdx.x < cg.active;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const long so = (long)g * Cp + cc * 8;
+    float sc[8], sh[8], wr[8];
+    load8f(scale + so, sc);
+    load8f(shift + so, sh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cc * 8 + i;
+        const float t = w[c < C ? c : 0];
+        wr[i] = c < C ? t : 0.f;
+    }
+    const float bias = b ? b[0] : 0.f;
+    // every lane walks the same number of rows (the shuffles below need all lanes of a pixel's group alive)
+    const int64_t n_it = (p1 - p0 + cg.rows - 1) / cg.rows;
+    for (int64_t it = 0; it < n_it; ++it) {
+        const int64_t p = p0 + it * cg.rows + prow;
+        const bool ok = act && p < p1;
+        float v[8];
+        unpack8(z[(ok ? p : p0) * cg.cpc + cc], v);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += act_to_f32(f32_to_act(fmaxf(v[i] * sc[i] + sh[i], 0.f))) * wr[i];
+        for (int o = cg.cpc >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (ok && cc == 0) y[p] = acc + bias;
+    }
+}
+
+// partials as bn_bwd_reduce_kernel; additionally dw[c] += sum_p dy[p] * a[p][c], db += sum_p dy[p] (one f32 atomic per block
+// and element, as outconv_bwd_dw_kernel)
+__global__ void bn_head_bwd_reduce_kernel(const uint4* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const float* __restrict__ w, float* __restrict__ partials, float* __restrict__ dw,
+                                          float* __restrict__ db, int64_t ppg, int Cp, int C, ColGeom cg, int blocks_per_group,
+                                          int64_t pix_per_block) {
+    extern __shared__ float red[];     // [rows][cpc*24 + 1]: (s1, s2) pairs, then dw, then db
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
+    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    const bool act = (int)threadIdx.x < cg.active;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const int width = cg.cpc * 24 + 1;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
+    if (act) {
+        const long so = (long)g * Cp + cc * 8;
+        float sc[8], sh[8], mu[8], rs[8], wr[8];
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cc * 8 + i;
+            const float t = w[c < C ? c : 0];
+            wr[i] = c < C ? t : 0.f;
+        }
+        int64_t p = p0 + prow;
+        for (; p + 3 * cg.rows < p1; p += 4 * cg.rows) {        // four pixel rows in flight
+            uint4 zq[4];
+            float gq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                zq[u] = z[(p + u * cg.rows) * cg.cpc + cc];
+                gq[u] = dy[p + u * cg.rows];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float zv[8];
+                unpack8(zq[u], zv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float yv = zv[i] * sc[i] + sh[i];
+                    const float g0 = yv > 0.f ? act_to_f32(f32_to_act(gq[u] * wr[i])) : 0.f;
+                    s1[i] += g0;
+                    s2[i] += g0 * (zv[i] - mu[i]) * rs[i];
+                    sw[i] += gq[u] * act_to_f32(f32_to_act(fmaxf(yv, 0.f)));
+                }
+                sb += gq[u];
+            }
+        }
+        for (; p < p1; p += cg.rows) {
+            float zv[8];
+            unpack8(z[p * cg.cpc + cc], zv);
+            const float gd = dy[p];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float yv = zv[i] * sc[i] + sh[i];
+                const float g0 = yv > 0.f ? act_to_f32(f32_to_act(gd * wr[i])) : 0.f;
+                s1[i] += g0;
+                s2[i] += g0 * (zv[i] - mu[i]) * rs[i];
+                sw[i] += gd * act_to_f32(f32_to_act(fmaxf(yv, 0.f)));
+            }
+            sb += gd;
+        }
+        float* r = red + prow * width;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r[cc * 16 + i * 2] = s1[i];
+            r[cc * 16 + i * 2 + 1] = s2[i];
+            r[cg.cpc * 16 + cc * 8 + i] = sw[i];
+        }
+        if (cc == 0) r[cg.cpc * 24] = sb;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < width; j += NT) {
+        float t = 0.f;
+        for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+        if (j < cg.cpc * 16) {
+            const int ch = j >> 1;
+            if (ch < Cp) partials[((long)blockIdx.x * Cp + ch) * 2 + (j & 1)] = t;
+        } else if (j < cg.cpc * 24) {
+            const int ch = j - cg.cpc * 16;
+            if (ch < C) atomicAdd(dw + ch, t);
+        } else {
+            atomicAdd(db, t);
+        }
+    }
+}
+
+__global__ void bn_head_bwd_apply_kernel(const uint4* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ sums, const float* __restrict__ w, uint4* __restrict__ dz, int64_t ppg,
+                                         int Cp, int C, ColGeom cg, int blocks_per_group, int64_t pix_per_block, float inv_n) {
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
+    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    if ((int)threadIdx.x >= cg.active) return;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const long so = (long)g * Cp + cc * 8;
+    float sc[8], sh[8], k1[8], k0[8], wr[8];
+    {
+        float mu[8], rs[8];
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s1 = sums[(so + i) * 2], s2 = sums[(so + i) * 2 + 1];
+            k1[i] = -sc[i] * rs[i] * s2 * inv_n;
+            k0[i] = -sc[i] * s1 * inv_n - k1[i] * mu[i];
+            const int c = cc * 8 + i;
+            const float t = w[c < C ? c : 0];
+            wr[i] = c < C ? t : 0.f;
+        }
+    }
+    int64_t p = p0 + prow;
+    for (; p + cg.rows < p1; p += 2 * cg.rows) {
+        const int64_t ia = p * cg.cpc + cc, ib = (p + cg.rows) * cg.cpc + cc;
+        const uint4 za = z[ia], zb = z[ib];
+        const float ga = dy[p], gb = dy[p + cg.rows];
+        float zv[8], zw[8], oa[8], ob[8];
+        unpack8(za, zv);
+        unpack8(zb, zw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            oa[i] = ((zv[i] * sc[i] + sh[i] > 0.f) ? sc[i] * act_to_f32(f32_to_act(ga * wr[i])) : 0.f) + k1[i] * zv[i] + k0[i];
+            ob[i] = ((zw[i] * sc[i] + sh[i] > 0.f) ? sc[i] * act_to_f32(f32_to_act(gb * wr[i])) : 0.f) + k1[i] * zw[i] + k0[i];
+        }
+        dz[ia] = pack8(oa);
+        dz[ib] = pack8(ob);
+    }
+    for (; p < p1; p += cg.rows) {
+        const int64_t ia = p * cg.cpc + cc;
+        float zv[8], oa[8];
+        unpack8(z[ia], zv);
+        const float ga = dy[p];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            oa[i] = ((zv[i] * sc[i] + sh[i] > 0.f) ? sc[i] * act_to_f32(f32_to_act(ga * wr[i])) : 0.f) + k1[i] * zv[i] + k0[i];
+        dz[ia] = pack8(oa);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ConvLSTM backward, point-wise part
 // ---------------------------------------------------------------------------------------------
 // Split-K form of the cell forward: pre-activations arrive as f32 [pixels][N] in gate-interleaved panel-row order
@@ -1190,6 +1386,69 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
     UCLSTM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, sums, (uint4*)dz, chunks, make_fastdiv(Cp / 8),
                        make_fastdiv((uint32_t)pixels_per_group), Cp, (float)(1.0 / (double)pixels_per_group));
+    return UCLSTM_OK;
+}
+
+// ---- output head fused into the last BatchNorm stage (Co = 1; see bn_head_fwd_kernel) ----
+static bool head_geom_ok(int Cp, int C) {
+    const int cpc = Cp / 8;
+    return Cp > 0 && (Cp % 8) == 0 && C > 0 && C <= Cp && cpc <= 64 && (cpc & (cpc - 1)) == 0;
+}
+static void head_blocks(int64_t pixels_per_group, int groups, int& bpg, int64_t& ppb) {
+    bpg = (int)((pixels_per_group + 127) / 128);
+    const int cap = (4096 + groups - 1) / groups;
+    if (bpg > cap) bpg = cap;
+    if (bpg < 1) bpg = 1;
+    ppb = (pixels_per_group + bpg - 1) / bpg;
+}
+
+extern "C" int32_t uclstm_bn_head_fwd(const void* z, const float* scale, const float* shift, const float* w, const float* b, float* y,
+                                      int64_t pixels, int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream) {
+    if (!aligned16(z) || !scale || !shift || !w || !y || pixels <= 0 || pixels_per_group <= 0 || (pixels % pixels_per_group) ||
+        !head_geom_ok(Cp, C))
+        return UCLSTM_E_BADARG;
+    if (pixels * (Cp / 8) >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    const int groups = (int)(pixels / pixels_per_group);
+    int bpg;
+    int64_t ppb;
+    head_blocks(pixels_per_group, groups, bpg, ppb);
+    UCLSTM_LAUNCH(bn_head_fwd_kernel, dim3(groups * bpg), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, scale, shift, w, b, y,
+                  pixels_per_group, Cp, C, cg, bpg, ppb);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_head_bwd_reduce(const void* z, const float* dy, const float* scale, const float* shift, const float* mean,
+                                             const float* rstd, const float* w, float* partials, float* sums, float* dw, float* db,
+                                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream) {
+    if (!aligned16(z) || !dy || !scale || !shift || !mean || !rstd || !w || !partials || !sums || !dw || !db || pixels <= 0 ||
+        pixels_per_group <= 0 || (pixels % pixels_per_group) || !head_geom_ok(Cp, C))
+        return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    const int groups = (int)(pixels / pixels_per_group);
+    const int bpg = bn_bwd_blocks_per_group(pixels_per_group, groups);          // = uclstm_bn_bwd_reduce_rows / groups
+    const int64_t ppb = (pixels_per_group + bpg - 1) / bpg;
+    const size_t lds = (size_t)cg.rows * (cg.cpc * 24 + 1) * sizeof(float);
+    UCLSTM_LAUNCH(bn_head_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, dy, scale, shift, mean,
+                  rstd, w, partials, dw, db, pixels_per_group, Cp, C, cg, bpg, ppb);
+    UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_head_bwd_apply(const void* z, const float* dy, const float* scale, const float* shift, const float* mean,
+                                            const float* rstd, const float* sums, const float* w, void* dz, int64_t pixels,
+                                            int64_t pixels_per_group, int32_t Cp, int32_t C, void* stream) {
+    if (!aligned16(z) || !aligned16(dz) || !dy || !scale || !shift || !mean || !rstd || !sums || !w || pixels <= 0 ||
+        pixels_per_group <= 0 || (pixels % pixels_per_group) || !head_geom_ok(Cp, C))
+        return UCLSTM_E_BADARG;
+    if (pixels * (Cp / 8) >= ((int64_t)1 << 31)) return UCLSTM_E_BADARG;
+    const ColGeom cg = col_geom(Cp);
+    const int groups = (int)(pixels / pixels_per_group);
+    int bpg;
+    int64_t ppb;
+    head_blocks(pixels_per_group, groups, bpg, ppb);
+    UCLSTM_LAUNCH(bn_head_bwd_apply_kernel, dim3(groups * bpg), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, dy, scale, shift, mean,
+                  rstd, sums, w, (uint4*)dz, pixels_per_group, Cp, C, cg, bpg, ppb, (float)(1.0 / (double)pixels_per_group));
     return UCLSTM_OK;
 }
 

@@ -135,7 +135,8 @@ class DoubleConv(nn.Module):
             nn.Conv2d(out_ch, out_ch, 3, padding=1), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True)
         )
 
-    def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False):
+    def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False, head=None):
+        """``head``: an ``nn.Conv2d(C, 1, 1)`` fused behind this stage (training mode): returns its f32 NCHW output."""
         training = self.training or not bn.track_running_stats
         if bn.momentum is not None:
             mom = bn.momentum
@@ -145,8 +146,12 @@ class DoubleConv(nn.Module):
             mom = -float(int(bn.num_batches_tracked) + 1)
         else:
             mom = 0.0
-        a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                 tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
+        if head is not None:
+            a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col, head.weight, head.bias)
+        else:
+            a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
         if training and bn.num_batches_tracked is not None:
             if _DEFERRED_COUNTERS is not None:
                 _DEFERRED_COUNTERS.append((bn.num_batches_tracked, groups))      # one multi-tensor add per model forward
@@ -155,12 +160,12 @@ class DoubleConv(nn.Module):
         return a
 
     def forward_nhwc(self, x0: Tensor, x1: Optional[Tensor] = None, c_valid=None, off=(0, 0), groups: int = 1,
-                     im2col: bool = False) -> Tensor:
+                     im2col: bool = False, head=None) -> Tensor:
         conv0, bn0, conv1, bn1 = self.net[0], self.net[1], self.net[3], self.net[4]
         if c_valid is None:
             c_valid = (conv0.in_channels,)
         a = self._stage(conv0, bn0, x0, x1, c_valid, off, groups, im2col)
-        return self._stage(conv1, bn1, a, None, (conv0.out_channels,), (0, 0), groups)
+        return self._stage(conv1, bn1, a, None, (conv0.out_channels,), (0, 0), groups, head=head)
 
     def first_layer_nhwc(self, x: Tensor, time_major: bool, groups: int) -> Tensor:
         """f32 NCHW (or [B,T,C,H,W] with ``time_major``) input that needs no gradient -> pre-gathered first conv."""
@@ -210,7 +215,7 @@ class Up(nn.Module):
         self.up = nn.ConvTranspose2d(in_ch, in_ch // 2, 2, stride=2)
         self.conv = DoubleConv(in_ch, out_ch)
 
-    def forward_nhwc(self, x1: Tensor, x2: Tensor, skip_ch: int, groups: int = 1) -> Tensor:
+    def forward_nhwc(self, x1: Tensor, x2: Tensor, skip_ch: int, groups: int = 1, head=None) -> Tensor:
         u = ops.ConvT2x2.apply(x1, self.up.weight, self.up.bias)
         diffY = x2.shape[1] - u.shape[1]
         diffX = x2.shape[2] - u.shape[2]
@@ -224,7 +229,7 @@ class Up(nn.Module):
             ww = min(u.shape[2] - l, x2.shape[2]) if diffX < 0 else u.shape[2]
             u = u[:, t:t + hh, l:l + ww, :].contiguous()
             diffY, diffX = max(diffY, 0), max(diffX, 0)
-        return self.conv.forward_nhwc(x2, u, (skip_ch, self.up.out_channels), (diffY // 2, diffX // 2), groups)
+        return self.conv.forward_nhwc(x2, u, (skip_ch, self.up.out_channels), (diffY // 2, diffX // 2), groups, head=head)
 
     def forward(self, x1, x2):
         a = self.forward_nhwc(ops.ToNHWC.apply(x1.contiguous().float()), ops.ToNHWC.apply(x2.contiguous().float()), x2.shape[1])
@@ -320,6 +325,14 @@ class TemporalUNetDualView(nn.Module):
             xb = self.attention.forward_nhwc(xb, self.base_ch * 16)
         return xb, (x3, x2, x1, x0)
 
+    def _head_fusable(self) -> bool:
+        """Training-mode forward that will be differentiated, ONE output channel, the last stage's channel chunks a power of two:
+        the conditions of ops.ConvBNReLU's fused output head (UCLSTM_FUSE_HEAD=0 switches it off)."""
+        bn = self.up0.conv.net[4]
+        cpc = ops.cpad(self.base_ch) // 8
+        return (ops.FUSE_HEAD and self.out_channels == 1 and (self.training or not bn.track_running_stats) and torch.is_grad_enabled()
+                and cpc <= 64 and (cpc & (cpc - 1)) == 0)
+
     def encode_once(self, x_t):
         """Reference train/unet.py:161-172 on f32 NCHW (public helper, one timestep)."""
         xb, (x3, x2, x1, x0) = self._encode_nhwc(x_t, False, 1)
@@ -386,8 +399,12 @@ class TemporalUNetDualView(nn.Module):
         d3 = self.up3.forward_nhwc(b_flat, x3, c * 8, T)
         d2 = self.up2.forward_nhwc(d3, x2, c * 4, T)
         d1 = self.up1.forward_nhwc(d2, x1, c * 2, T)
-        d0 = self.up0.forward_nhwc(d1, x0, c, T)
-        y = self.outc.forward_nhwc(d0).view(T, B, self.out_channels, H, W)
+        if self._head_fusable():
+            # up0's second stage and the 1x1 output convolution as one op: that activation and its gradient never exist in memory
+            y = self.up0.forward_nhwc(d1, x0, c, T, head=self.outc.conv).view(T, B, self.out_channels, H, W)
+        else:
+            d0 = self.up0.forward_nhwc(d1, x0, c, T)
+            y = self.outc.forward_nhwc(d0).view(T, B, self.out_channels, H, W)
         # a plain list of T frames like the reference's (train/unet.py:200-203); it also carries the frames already laid out
         # as [B,T,C,H,W] (a view) so that the training loop's torch.stack(output, dim=1) costs no copy kernels and its backward
         # is one transpose instead of T zero-fill + accumulate pairs

@@ -1165,7 +1165,9 @@ class ConvBNReLU(_GradAwareFunction):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, gamma, beta, running_mean, running_var, c_valid, off, groups, training, momentum, eps,
-                im2col):
+                im2col, head_w=None, head_b=None):
+        # head_w / head_b: the model's 1x1 output convolution (ONE output channel) fused into this stage (training mode only,
+        # uclstm_bn_head_*): the stage then returns y f32 [n_img, 1, H, W] instead of its activation, which never exists.
         _dev(x0, ACT, "x0")
         Co, Ci_total = weight.shape[0], weight.shape[1]
         Cop = cpad(Co)
@@ -1208,13 +1210,21 @@ class ConvBNReLU(_GradAwareFunction):
                 L.check(L.lib.uclstm_bn_finalize(_p(stats), groups, tpg, Cop, Co, ppg, _p(gamma), _p(beta), _p(running_mean),
                                                  _p(running_var), momentum, eps, _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
                                                  _stream()), "bn_finalize")
-            a = torch.empty_like(z)
-            _timed_hbm("bn_apply_relu", 4.0 * z.numel(),        # 2 B read + 2 B written per element
-                       lambda: L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
-                                       "bn_apply_relu"))
-            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
+            if head_w is not None:
+                a = torch.empty((n_img, 1, H, W), dtype=F32, device=dev)
+                _timed_hbm("bn_head_fwd", 2.0 * z.numel() + 4.0 * n_img * H * W,
+                           lambda: L.check(K.uclstm_bn_head_fwd(_p(z), _p(par[0]), _p(par[1]), _p(head_w), _p(head_b), _p(a), n_img * H * W, ppg,
+                                                                Cop, Co, _stream()), "bn_head_fwd"))
+            else:
+                a = torch.empty_like(z)
+                _timed_hbm("bn_apply_relu", 4.0 * z.numel(),        # 2 B read + 2 B written per element
+                           lambda: L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, ppg, Cop, _stream()),
+                                           "bn_apply_relu"))
+            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias, head_w, head_b)
             if need_bw:
-                note_use(weight, gamma, beta, bias)
+                note_use(weight, gamma, beta, bias, head_w, head_b)
+        elif head_w is not None:
+            raise L.UclstmError("ConvBNReLU: the fused output head is a training-mode path")
         elif need_bw:
             join_forward_side(dev)
             # evaluation-mode statistics WITH a backward pass (fine-tuning through frozen BatchNorm): keep the pre-BN conv
@@ -1228,7 +1238,7 @@ class ConvBNReLU(_GradAwareFunction):
             a = torch.empty_like(z)
             L.check(K.uclstm_bn_apply_relu(_p(z), _p(a), _p(par[0]), _p(par[1]), n_img * H * W, n_img * H * W, Cop, _stream()),
                     "bn_apply_relu")
-            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias)
+            ctx.save_for_backward(x0, x1, weight, z, par, gamma, beta, bias, None, None)
             note_use(weight, gamma, beta, bias)
         else:
             join_forward_side(dev)
@@ -1236,31 +1246,53 @@ class ConvBNReLU(_GradAwareFunction):
             a = out
             igemm_store(srcs, wp, (H, W), n_img, [(a, 0, Cop, 0, 1, 0, 0)], ktap=ktap, pad=pad, groups=1, bias=bp,
                         col_scale=par[0], col_shift=par[1], relu=True)
-            ctx.save_for_backward(x0, x1, weight, None, None, gamma, beta, bias)
+            ctx.save_for_backward(x0, x1, weight, None, None, gamma, beta, bias, None, None)
         ctx.cfg = (tuple(c_valid), tuple(off), groups, training, im2col, Co, Ci_total, bias is not None)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x0, x1, weight, z, par, gamma, beta, bias = ctx.saved_tensors
+        x0, x1, weight, z, par, gamma, beta, bias, head_w, head_b = ctx.saved_tensors
         c_valid, off, groups, training, im2col, Co, Ci_total, has_bias = ctx.cfg
-        da = da.contiguous()
         n_img, H, W, Cop = z.shape
         dev = z.device
         pixels, ppg = n_img * H * W, (n_img // groups) * H * W
         sums = torch.empty((groups, Cop, 2), dtype=F32, device=dev)
         partials = torch.empty((int(L.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg)), Cop, 2), dtype=F32, device=dev)
         K = _k(z)
-        _timed_hbm("bn_bwd_reduce", 4.0 * z.numel(),            # z and da read once
-                   lambda: L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials), _p(sums),
-                                                          pixels, ppg, Cop, _stream()), "bn_bwd_reduce"))
         dz = torch.empty_like(z)
-        # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
-        # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
-        sums_dz = sums if training else torch.zeros_like(sums)
-        _timed_hbm("bn_bwd_apply", 6.0 * z.numel(),             # z, da read, dz written
-                   lambda: L.check(K.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz), _p(dz),
-                                                         pixels, ppg, Cop, _stream()), "bn_bwd_apply"))
+        d_head_w = d_head_b = None
+        if head_w is not None:
+            # fused output head: `da` is dy f32 [n_img, 1, H, W]; the activation gradient bf16(dy * w) is formed on the fly
+            dy = _dev(da.contiguous().float(), F32, "dy")
+            gw, gb = direct_grad(head_w), (direct_grad(head_b) if head_b is not None else None)
+            direct = gw is not None and gw.is_contiguous() and (head_b is None or gb is not None)
+            dwh = gw if direct else torch.zeros_like(head_w, memory_format=torch.contiguous_format)
+            dbh = gb if (direct and head_b is not None) else torch.zeros((1,), dtype=F32, device=dev)
+            _timed_hbm("bn_head_bwd_reduce", 2.0 * z.numel() + 4.0 * pixels,
+                       lambda: L.check(K.uclstm_bn_head_bwd_reduce(_p(z), _p(dy), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(head_w),
+                                                                   _p(partials), _p(sums), _p(dwh), _p(dbh), pixels, ppg, Cop, Co, _stream()),
+                                       "bn_head_bwd_reduce"))
+            _timed_hbm("bn_head_bwd_apply", 4.0 * z.numel() + 4.0 * pixels,
+                       lambda: L.check(K.uclstm_bn_head_bwd_apply(_p(z), _p(dy), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums),
+                                                                  _p(head_w), _p(dz), pixels, ppg, Cop, Co, _stream()), "bn_head_bwd_apply"))
+            if direct:
+                grad_written(head_w)
+                if head_b is not None:
+                    grad_written(head_b)
+            else:
+                d_head_w, d_head_b = dwh, (dbh if head_b is not None else None)
+        else:
+            da = da.contiguous()
+            _timed_hbm("bn_bwd_reduce", 4.0 * z.numel(),            # z and da read once
+                       lambda: L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials),
+                                                              _p(sums), pixels, ppg, Cop, _stream()), "bn_bwd_reduce"))
+            # training: dz = scale*(g - s1/n - xhat*s2/n).  Evaluation-mode statistics are constants, the two mean terms vanish:
+            # the same kernel with zero sums gives dz = scale*g (sums itself still holds dbeta / dgamma)
+            sums_dz = sums if training else torch.zeros_like(sums)
+            _timed_hbm("bn_bwd_apply", 6.0 * z.numel(),             # z, da read, dz written
+                       lambda: L.check(K.uclstm_bn_bwd_apply(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(sums_dz),
+                                                             _p(dz), pixels, ppg, Cop, _stream()), "bn_bwd_apply"))
         # training: the conv bias feeds BatchNorm, which removes any per-channel constant -- its gradient is analytically 0.
         # With frozen statistics it is the column sum of dz.
         bias_grad = (lambda: colsum(dz)[:Co].contiguous()) if not training else (lambda: torch.zeros((Co,), dtype=F32, device=dev))
@@ -1322,7 +1354,7 @@ class ConvBNReLU(_GradAwareFunction):
             wd = pack_weights(dd, weight, c_valid[0] * 9, dz.dtype)
             dx1 = torch.empty_like(x1)
             igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx1, 0, dd.N, 0, 1, -off[0], -off[1])], ktap=3, pad=1)
-        return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, d_head_w, d_head_b
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1677,6 +1709,7 @@ class ConvLSTMSeq(torch.autograd.Function):
 # the other; they do not depend on each other)
 # ---------------------------------------------------------------------------------------------
 GROUP_LSTM = os.environ.get("UCLSTM_GROUP_LSTM", "1") != "0"
+FUSE_HEAD = os.environ.get("UCLSTM_FUSE_HEAD", "1") != "0"          # 1x1 output convolution fused into the last BatchNorm stage (training)
 _GROUP_PLANS: dict = {}
 _CUS = 256
 _BLOCK_OVERHEAD_STEPS = 12.0          # prologue + epilogue of a patch-shape block in units of one K-step (~10 us / 0.87 us)
