@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UCLSTM_ABI_VERSION 14
+#define UCLSTM_ABI_VERSION 15
 
 #define UCLSTM_OK            0
 #define UCLSTM_E_BADARG     -1   /* shape / alignment / null-pointer contract violated      */
@@ -256,6 +256,23 @@ int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const float* scale, c
                             const float* mean, const float* rstd, const float* sums, void* dz,
                             int64_t pixels, int64_t pixels_per_group, int32_t Cp, void* stream);
 
+/* MaxPool2d(2) fused into the BatchNorm stage that feeds it (the second stage of inc / down1..3; train/unet.py:81, :166-169: every
+ * encoder block output goes to the next block's pooling AND to the decoder's skip connection).  H and W even.
+ *   uclstm_bn_apply_relu_pool:  a = bf16(relu(z*scale + shift)) as uclstm_bn_apply_relu, and p = max over each 2x2 window of a.
+ *   backward: the gradient of a is dskip (bf16, same shape as a; NULL = none) + scatter(dp) to the window's first maximum in scan
+ *   order (ATen's rule, uclstm_maxpool2_bwd), rounded to bf16 as that kernel would have stored it -- formed on the fly inside the
+ *   BatchNorm backward reduction / apply (same partials / sums / dz contract as uclstm_bn_bwd_reduce / _apply; `partials` has
+ *   uclstm_bn_pool_bwd_rows() rows), with the arg-max recomputed from z. */
+int64_t uclstm_bn_pool_bwd_rows(int64_t n_img, int32_t H, int32_t W, int32_t Cp, int32_t groups);
+int32_t uclstm_bn_apply_relu_pool(const void* z, void* a, void* p, const float* scale, const float* shift, int64_t n_img, int32_t H,
+                                  int32_t W, int32_t Cp, int32_t groups, void* stream);
+int32_t uclstm_bn_pool_bwd_reduce(const void* z, const void* dskip, const void* dp, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, float* partials, float* sums, int64_t n_img, int32_t H,
+                                  int32_t W, int32_t Cp, int32_t groups, void* stream);
+int32_t uclstm_bn_pool_bwd_apply(const void* z, const void* dskip, const void* dp, const float* scale, const float* shift,
+                                 const float* mean, const float* rstd, const float* sums, void* dz, int64_t n_img, int32_t H,
+                                 int32_t W, int32_t Cp, int32_t groups, void* stream);
+
 /* The model's output head fused into its last BatchNorm stage (up0's second conv -> BatchNorm -> ReLU -> OutConv 1x1 with ONE
  * output channel; train/unet.py:70-71, :101-107, :196-199).  That activation feeds only the output convolution: unfused, a training
  * step makes six passes over the largest tensor of the model for it and its gradient; fused, neither exists in memory.
@@ -449,6 +466,9 @@ UCLSTM_F16_TWIN(uclstm_pack_weights_batched)
 UCLSTM_F16_TWIN(uclstm_bn_apply_relu)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_reduce)
 UCLSTM_F16_TWIN(uclstm_bn_bwd_apply)
+UCLSTM_F16_TWIN(uclstm_bn_apply_relu_pool)
+UCLSTM_F16_TWIN(uclstm_bn_pool_bwd_reduce)
+UCLSTM_F16_TWIN(uclstm_bn_pool_bwd_apply)
 UCLSTM_F16_TWIN(uclstm_bn_head_fwd)
 UCLSTM_F16_TWIN(uclstm_bn_head_bwd_reduce)
 UCLSTM_F16_TWIN(uclstm_bn_head_bwd_apply)

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 29
     bound = set(L._PROTOS) | {n + "_f16" for n in L.F16_TWINS}          # the fp16 twins share their prototype's binding
     assert set(syms) == bound, (set(syms) ^ bound)
-    assert len(L.F16_TWINS) == 26 and all(n in L._PROTOS for n in L.F16_TWINS)
+    assert len(L.F16_TWINS) == 29 and all(n in L._PROTOS for n in L.F16_TWINS)
     assert L.kernels(torch.bfloat16) is L.lib and L.kernels(torch.float16).uclstm_igemm_fwd is not L.lib.uclstm_igemm_fwd
     assert L.kernels(torch.float16).uclstm_bn_finalize is L.lib.uclstm_bn_finalize            # shared (f32-only) entry point
     raw = C.CDLL(L.LIB_PATH)

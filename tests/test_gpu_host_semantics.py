@@ -291,3 +291,33 @@ def test_up_with_a_skip_smaller_or_larger_than_the_upsampled_map(skip_hw):
             assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) < 1e-3
             continue
         assert rel_l2(p.grad.cpu(), r) <= 3e-2, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("base,use_skip", [(8, True), (64, True), (24, False)])
+def test_maxpool_fused_into_the_batchnorm_stage_matches_the_separate_kernels(dtype, base, use_skip):
+    """DoubleConv whose second BatchNorm stage also writes MaxPool2d(2) of its activation and takes (skip gradient, pooled
+    gradient) back inside the BatchNorm backward kernels (uclstm_bn_apply_relu_pool / uclstm_bn_pool_bwd_*), against
+    bn_apply_relu -> maxpool forward / maxpool backward -> BatchNorm backward: activation and pooled tensor bit-identical (same
+    rounding points), gradients to f32 summation order; with and without a gradient on the skip branch."""
+    from unet_convlstm_amd import ops
+    res = {}
+    for fuse in (True, False):
+        torch.manual_seed(1)
+        dc = U.DoubleConv(3, base).to(DEV).train()
+        x = torch.randn(4, 3, 32, 32, device=DEV).requires_grad_(True)
+        with ops.compute_dtype(dtype):
+            xa = ops.ToNHWC.apply(x)
+            if fuse:
+                a, p = dc.forward_nhwc(xa, groups=2, pool=True)
+            else:
+                a = dc.forward_nhwc(xa, groups=2)
+                p, a = ops.MaxPool2Skip.apply(a)
+            loss = (p.float() * 1.5).sum() + ((a.float() ** 2).sum() if use_skip else 0.0)
+            loss.backward()
+        res[fuse] = (a.detach().float().cpu(), p.detach().float().cpu(), x.grad.cpu(), {k: v.grad.cpu() for k, v in dc.named_parameters()})
+    A, B = res[True], res[False]
+    assert torch.equal(A[0], B[0]) and torch.equal(A[1], B[1])
+    errs = {"dx": rel_l2(A[2], B[2]), **{k: rel_l2(A[3][k], B[3][k]) for k in A[3] if float(B[3][k].abs().max()) > 0}}
+    print(f"[parity] pooling fused into BatchNorm ({dtype}, {base} channels, skip gradient {use_skip}): " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) <= 1e-3, errs

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCLSTM_LIB") or os.path.join(HERE, "libuclstm.so")
 HEADER_PATH = os.path.join(HERE, "..", "include", "uclstm.h")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 EPI_STORE, EPI_LSTM, EPI_ATOMIC = 0, 1, 2
 NMODE_IDENTITY, NMODE_LSTM, NMODE_TAPMAJOR = 0, 1, 2
 KMODE_IDENTITY, KMODE_GATES, KMODE_IM2COL = 0, 1, 2
@@ -113,6 +113,10 @@ _PROTOS = {
     "uclstm_bn_bwd_reduce_rows": [_L, _L],
     "uclstm_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
     "uclstm_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P],
+    "uclstm_bn_pool_bwd_rows": [_L, _I, _I, _I, _I],
+    "uclstm_bn_apply_relu_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "uclstm_bn_pool_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "uclstm_bn_pool_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "uclstm_bn_head_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
     "uclstm_bn_head_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
     "uclstm_bn_head_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
@@ -149,11 +153,11 @@ _PROTOS = {
     "uclstm_source_hash": [],
     "uclstm_last_error_string": [],
 }
-_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_source_hash": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64}
+_RESTYPES = {"uclstm_build_arch": C.c_char_p, "uclstm_source_hash": C.c_char_p, "uclstm_last_error_string": C.c_char_p, "uclstm_bn_bwd_reduce_rows": C.c_int64, "uclstm_bn_pool_bwd_rows": C.c_int64}
 
 
 # entry points that exist twice: name (bfloat16) and name_f16 (IEEE binary16), identical signatures (include/uclstm.h)
-F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_fwd_group', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_pack_weights_batched', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_bn_head_fwd', 'uclstm_bn_head_bwd_reduce', 'uclstm_bn_head_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_lstm_fwd_pointwise_group', 'uclstm_splitk_finish', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
+F16_TWINS = ['uclstm_igemm_fwd', 'uclstm_igemm_fwd_group', 'uclstm_igemm_wgrad', 'uclstm_pack_weights', 'uclstm_pack_weights_batched', 'uclstm_bn_apply_relu', 'uclstm_bn_bwd_reduce', 'uclstm_bn_bwd_apply', 'uclstm_bn_apply_relu_pool', 'uclstm_bn_pool_bwd_reduce', 'uclstm_bn_pool_bwd_apply', 'uclstm_bn_head_fwd', 'uclstm_bn_head_bwd_reduce', 'uclstm_bn_head_bwd_apply', 'uclstm_maxpool2_fwd', 'uclstm_maxpool2_bwd', 'uclstm_lstm_bwd_pointwise', 'uclstm_lstm_fwd_pointwise', 'uclstm_lstm_fwd_pointwise_group', 'uclstm_splitk_finish', 'uclstm_nchw_to_nhwc', 'uclstm_nhwc_to_nchw', 'uclstm_nchw_grad_to_nhwc', 'uclstm_im2col3x3_first', 'uclstm_outconv_fwd', 'uclstm_outconv_bwd', 'uclstm_colsum', 'uclstm_attention_fwd', 'uclstm_attention_bwd']
 
 
 def header_symbols() -> list[str]:

@@ -19,6 +19,9 @@
 #define uclstm_bn_bwd_reduce uclstm_bn_bwd_reduce_f16
 #define uclstm_bn_bwd_apply uclstm_bn_bwd_apply_f16
 #define uclstm_bn_head_fwd uclstm_bn_head_fwd_f16
+#define uclstm_bn_apply_relu_pool uclstm_bn_apply_relu_pool_f16
+#define uclstm_bn_pool_bwd_reduce uclstm_bn_pool_bwd_reduce_f16
+#define uclstm_bn_pool_bwd_apply uclstm_bn_pool_bwd_apply_f16
 #define uclstm_bn_head_bwd_reduce uclstm_bn_head_bwd_reduce_f16
 #define uclstm_bn_head_bwd_apply uclstm_bn_head_bwd_apply_f16
 #define uclstm_maxpool2_fwd uclstm_maxpool2_fwd_f16

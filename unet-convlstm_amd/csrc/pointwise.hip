@@ -218,6 +218,8 @@ static ColGeom col_geom(int Cp) {
 // partials[g*blocks_per_group + bi][c][0..1] = this block's (sum g_, sum g_*xhat).  No atomics: the run-to-run order of f32
 // atomic adds here changed the whole gradient by ~1e-3 (the sums feed dz, and BatchNorm backward at random init amplifies
 // 1e-7 perturbations through its act16 roundings layer after layer); bn_bwd_sum_kernel adds the rows in a fixed order.
+// (no launch bounds on purpose: at 128 VGPRs / four waves per SIMD the kernel spills 36 bytes per lane and runs 4.2 TB/s; with
+// __launch_bounds__(256) it does not spill, drops to two or three waves per SIMD and runs 3.3 TB/s)
 __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ da, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, float* __restrict__ partials, int64_t ppg, int Cp, ColGeom cg,
@@ -467,6 +469,208 @@ __global__ void maxpool_bwd_kernel(const uint4* __restrict__ a, const uint4* __r
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) da[b0 + offs[k]] = pack8(o[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2) fused into the BatchNorm stage that feeds it (the second stage of inc / down1..3: train/unet.py:81, :166-169)
+// ---------------------------------------------------------------------------------------------
+// Every encoder block output is used twice: by the next block's pooling and by the decoder's skip connection.  Unfused, the
+// forward pass re-reads the activation to pool it, and the backward pass runs a kernel that scatters the pooled gradient,
+// adds the skip gradient and WRITES the sum, which the BatchNorm backward reduction and apply then each read again.
+// Fused: bn_apply_relu writes the pooled tensor too; the BatchNorm backward kernels take (skip gradient, pooled gradient),
+// recompute the stored activation a = act16(relu(z*scale + shift)) of the 2x2 window from z to find the arg-max (first maximum in
+// scan order, strict '>': ATen's rule, as maxpool_bwd_kernel) and form da = act16(skip + scatter(dp)) on the fly.
+// Thread = one 16-byte channel chunk of `rows` interleaved 2x2 WINDOWS of one BatchNorm group (H, W even).
+struct PoolGeom {
+    int H, W, Ho, Wo;
+    FastDiv dWo, dHoWo;
+    int64_t wpg;           // windows per group = images per group * Ho * Wo
+};
+__device__ __forceinline__ int64_t pool_base(const PoolGeom& pg, int64_t wi, int cpc, int cc) {
+    const uint32_t img = fdiv((uint32_t)wi, pg.dHoWo);
+    const uint32_t r = (uint32_t)wi - img * pg.dHoWo.d;
+    const uint32_t yo = fdiv(r, pg.dWo);
+    const uint32_t xo = r - yo * pg.Wo;
+    return (((int64_t)img * pg.H + 2 * yo) * pg.W + 2 * xo) * cpc + cc;
+}
+
+__global__ void bn_apply_relu_pool_kernel(const uint4* __restrict__ z, uint4* __restrict__ a, uint4* __restrict__ pl,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int Cp, ColGeom cg,
+                                          PoolGeom pg, int blocks_per_group, int64_t win_per_block) {
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t w0 = (int64_t)g * pg.wpg + (int64_t)bi * win_per_block;
+    const int64_t w1 = min((int64_t)(g + 1) * pg.wpg, w0 + win_per_block);
+    if ((int)threadIdx.x >= cg.active) return;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const long so = (long)g * Cp + cc * 8;
+    float sc[8], sh[8];
+    load8f(scale + so, sc);
+    load8f(shift + so, sh);
+    const int64_t offs[4] = {0, cg.cpc, (int64_t)pg.W * cg.cpc, (int64_t)pg.W * cg.cpc + cg.cpc};
+    for (int64_t wi = w0 + prow; wi < w1; wi += cg.rows) {
+        const int64_t b0 = pool_base(pg, wi, cg.cpc, cc);
+        uint4 zq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zq[k] = z[b0 + offs[k]];
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // post-ReLU values are >= 0: zero is the identity of this max
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[8];
+            unpack8(zq[k], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = act_to_f32(f32_to_act(fmaxf(v[i] * sc[i] + sh[i], 0.f)));       // the STORED activation
+                m[i] = fmaxf(m[i], v[i]);
+            }
+            a[b0 + offs[k]] = pack8(v);
+        }
+        pl[wi * cg.cpc + cc] = pack8(m);
+    }
+}
+
+// da of the window's four pixels: act16(skip + (k == argmax ? dp : 0)), as maxpool_bwd_kernel stores it
+__device__ __forceinline__ void pool_window_grad(const uint4 (&zq)[4], const uint4 (&sq)[4], bool has_skip, const uint4& dq, const float (&sc)[8],
+                                                 const float (&sh)[8], float (&zv)[4][8], float (&da)[4][8]) {
+    float av[4][8], g[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unpack8(zq[k], zv[k]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[k][i] = act_to_f32(f32_to_act(fmaxf(zv[k][i] * sc[i] + sh[i], 0.f)));
+    }
+    unpack8(dq, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int best = 0;
+        float m = av[0][i];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (av[k][i] > m) {
+                m = av[k][i];
+                best = k;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) da[k][i] = (k == best) ? g[i] : 0.f;
+    }
+    if (has_skip) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s8[8];
+            unpack8(sq[k], s8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) da[k][i] = act_to_f32(f32_to_act(da[k][i] + s8[i]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* __restrict__ dskip, const uint4* __restrict__ dp,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, float* __restrict__ partials, int Cp, ColGeom cg, PoolGeom pg,
+                                          int blocks_per_group, int64_t win_per_block) {
+    extern __shared__ float red[];     // [rows][cpc*16]
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t w0 = (int64_t)g * pg.wpg + (int64_t)bi * win_per_block;
+    const int64_t w1 = min((int64_t)(g + 1) * pg.wpg, w0 + win_per_block);
+    const bool act = (int)threadIdx.x < cg.active;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+        const long so = (long)g * Cp + cc * 8;
+        float sc[8], sh[8], mu[8], rs[8];
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+        const int64_t offs[4] = {0, cg.cpc, (int64_t)pg.W * cg.cpc, (int64_t)pg.W * cg.cpc + cg.cpc};
+        for (int64_t wi = w0 + prow; wi < w1; wi += cg.rows) {
+            const int64_t b0 = pool_base(pg, wi, cg.cpc, cc);
+            uint4 zq[4], sq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                zq[k] = z[b0 + offs[k]];
+                sq[k] = dskip ? dskip[b0 + offs[k]] : make_uint4(0, 0, 0, 0);
+            }
+            const uint4 dq = dp[wi * cg.cpc + cc];
+            float zv[4][8], da[4][8];
+            pool_window_grad(zq, sq, dskip != nullptr, dq, sc, sh, zv, da);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float g0 = (zv[k][i] * sc[i] + sh[i] > 0.f) ? da[k][i] : 0.f;
+                    s1[i] += g0;
+                    s2[i] += g0 * (zv[k][i] - mu[i]) * rs[i];
+                }
+        }
+    }
+    const int width = cg.cpc * 16;
+    if (act) {
+        float* r = red + prow * width + cc * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r[i * 2] = s1[i];
+            r[i * 2 + 1] = s2[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < width; j += NT) {
+        float t = 0.f;
+        for (int r = 0; r < cg.rows; ++r) t += red[r * width + j];
+        const int ch = j >> 1;
+        if (ch < Cp) partials[((long)blockIdx.x * Cp + ch) * 2 + (j & 1)] = t;
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_pool_bwd_apply_kernel(const uint4* __restrict__ z, const uint4* __restrict__ dskip, const uint4* __restrict__ dp,
+                                         const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ sums, uint4* __restrict__ dz, int Cp,
+                                         ColGeom cg, PoolGeom pg, int blocks_per_group, int64_t win_per_block, float inv_n) {
+    const int g = blockIdx.x / blocks_per_group;
+    const int bi = blockIdx.x - g * blocks_per_group;
+    const int64_t w0 = (int64_t)g * pg.wpg + (int64_t)bi * win_per_block;
+    const int64_t w1 = min((int64_t)(g + 1) * pg.wpg, w0 + win_per_block);
+    if ((int)threadIdx.x >= cg.active) return;
+    const int cc = threadIdx.x % cg.cpc;
+    const int prow = threadIdx.x / cg.cpc;
+    const long so = (long)g * Cp + cc * 8;
+    float sc[8], sh[8], k1[8], k0[8];
+    {
+        float mu[8], rs[8];
+        load8f(scale + so, sc);
+        load8f(shift + so, sh);
+        load8f(mean + so, mu);
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s1 = sums[(so + i) * 2], s2 = sums[(so + i) * 2 + 1];
+            k1[i] = -sc[i] * rs[i] * s2 * inv_n;
+            k0[i] = -sc[i] * s1 * inv_n - k1[i] * mu[i];
+        }
+    }
+    const int64_t offs[4] = {0, cg.cpc, (int64_t)pg.W * cg.cpc, (int64_t)pg.W * cg.cpc + cg.cpc};
+    for (int64_t wi = w0 + prow; wi < w1; wi += cg.rows) {
+        const int64_t b0 = pool_base(pg, wi, cg.cpc, cc);
+        uint4 zq[4], sq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            zq[k] = z[b0 + offs[k]];
+            sq[k] = dskip ? dskip[b0 + offs[k]] : make_uint4(0, 0, 0, 0);
+        }
+        const uint4 dq = dp[wi * cg.cpc + cc];
+        float zv[4][8], da[4][8];
+        pool_window_grad(zq, sq, dskip != nullptr, dq, sc, sh, zv, da);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = ((zv[k][i] * sc[i] + sh[i] > 0.f) ? sc[i] * da[k][i] : 0.f) + k1[i] * zv[k][i] + k0[i];
+            dz[b0 + offs[k]] = pack8(o);
+        }
     }
 }
 
@@ -1386,6 +1590,68 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
     UCLSTM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(chunks)), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)da,
                        scale, shift, mean, rstd, sums, (uint4*)dz, chunks, make_fastdiv(Cp / 8),
                        make_fastdiv((uint32_t)pixels_per_group), Cp, (float)(1.0 / (double)pixels_per_group));
+    return UCLSTM_OK;
+}
+
+// ---- MaxPool2d(2) fused into the BatchNorm stage that feeds it (see bn_apply_relu_pool_kernel) ----
+static bool pool_plan(int64_t n_img, int H, int W, int Cp, int groups, ColGeom& cg, PoolGeom& pg, int& bpg, int64_t& wpb) {
+    if (n_img <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || groups <= 0 || (n_img % groups) || Cp <= 0 || (Cp % 8) || Cp / 8 > NT) return false;
+    if (n_img * H * W * (Cp / 8) >= ((int64_t)1 << 31)) return false;
+    cg = col_geom(Cp);
+    pg.H = H; pg.W = W; pg.Ho = H / 2; pg.Wo = W / 2;
+    pg.dWo = make_fastdiv((uint32_t)pg.Wo);
+    pg.dHoWo = make_fastdiv((uint32_t)(pg.Ho * pg.Wo));
+    pg.wpg = (n_img / groups) * (int64_t)pg.Ho * pg.Wo;
+    bpg = (int)((pg.wpg + 31) / 32);                     // >= 32 windows (128 pixels) per thread row
+    const int cap = (4096 + groups - 1) / groups;
+    if (bpg > cap) bpg = cap;
+    if (bpg < 1) bpg = 1;
+    wpb = (pg.wpg + bpg - 1) / bpg;
+    return true;
+}
+
+#ifndef UCLSTM_ACT_F16
+extern "C" int64_t uclstm_bn_pool_bwd_rows(int64_t n_img, int32_t H, int32_t W, int32_t Cp, int32_t groups) {
+    ColGeom cg; PoolGeom pg; int bpg; int64_t wpb;
+    if (!pool_plan(n_img, H, W, Cp, groups, cg, pg, bpg, wpb)) return UCLSTM_E_BADARG;
+    return (int64_t)groups * bpg;
+}
+#endif
+
+extern "C" int32_t uclstm_bn_apply_relu_pool(const void* z, void* a, void* p, const float* scale, const float* shift, int64_t n_img,
+                                             int32_t H, int32_t W, int32_t Cp, int32_t groups, void* stream) {
+    ColGeom cg; PoolGeom pg; int bpg; int64_t wpb;
+    if (!aligned16(z) || !aligned16(a) || !aligned16(p) || !scale || !shift || !pool_plan(n_img, H, W, Cp, groups, cg, pg, bpg, wpb))
+        return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(bn_apply_relu_pool_kernel, dim3(groups * bpg), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (uint4*)a, (uint4*)p, scale,
+                  shift, Cp, cg, pg, bpg, wpb);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_pool_bwd_reduce(const void* z, const void* dskip, const void* dp, const float* scale, const float* shift,
+                                             const float* mean, const float* rstd, float* partials, float* sums, int64_t n_img, int32_t H,
+                                             int32_t W, int32_t Cp, int32_t groups, void* stream) {
+    ColGeom cg; PoolGeom pg; int bpg; int64_t wpb;
+    if (!aligned16(z) || !aligned16(dp) || (dskip && !aligned16(dskip)) || !scale || !shift || !mean || !rstd || !partials || !sums ||
+        !pool_plan(n_img, H, W, Cp, groups, cg, pg, bpg, wpb))
+        return UCLSTM_E_BADARG;
+    const size_t lds = (size_t)cg.rows * cg.cpc * 16 * sizeof(float);
+    UCLSTM_LAUNCH(bn_pool_bwd_reduce_kernel, dim3(groups * bpg), dim3(NT), lds, (hipStream_t)stream, (const uint4*)z, (const uint4*)dskip,
+                  (const uint4*)dp, scale, shift, mean, rstd, partials, Cp, cg, pg, bpg, wpb);
+    UCLSTM_LAUNCH(bn_bwd_sum_kernel, dim3((Cp * 2 + 31) / 32, groups), dim3(256), 0, (hipStream_t)stream, partials, sums, bpg, Cp);
+    return UCLSTM_OK;
+}
+
+extern "C" int32_t uclstm_bn_pool_bwd_apply(const void* z, const void* dskip, const void* dp, const float* scale, const float* shift,
+                                            const float* mean, const float* rstd, const float* sums, void* dz, int64_t n_img, int32_t H,
+                                            int32_t W, int32_t Cp, int32_t groups, void* stream) {
+    ColGeom cg; PoolGeom pg; int bpg; int64_t wpb;
+    if (!aligned16(z) || !aligned16(dp) || !aligned16(dz) || (dskip && !aligned16(dskip)) || !scale || !shift || !mean || !rstd || !sums ||
+        !pool_plan(n_img, H, W, Cp, groups, cg, pg, bpg, wpb))
+        return UCLSTM_E_BADARG;
+    UCLSTM_LAUNCH(bn_pool_bwd_apply_kernel, dim3(groups * bpg), dim3(NT), 0, (hipStream_t)stream, (const uint4*)z, (const uint4*)dskip,
+                  (const uint4*)dp, scale, shift, mean, rstd, sums, (uint4*)dz, Cp, cg, pg, bpg, wpb,
+                  (float)(1.0 / (double)((n_img / groups) * (int64_t)H * W)));
     return UCLSTM_OK;
 }
 

@@ -135,8 +135,9 @@ class DoubleConv(nn.Module):
             nn.Conv2d(out_ch, out_ch, 3, padding=1), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True)
         )
 
-    def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False, head=None):
-        """``head``: an ``nn.Conv2d(C, 1, 1)`` fused behind this stage (training mode): returns its f32 NCHW output."""
+    def _stage(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x0, x1, c_valid, off, groups, im2col=False, head=None, pool=False):
+        """``head``: an ``nn.Conv2d(C, 1, 1)`` fused behind this stage (training mode): returns its f32 NCHW output.
+        ``pool``: returns ``(activation, MaxPool2d(2)(activation))``."""
         training = self.training or not bn.track_running_stats
         if bn.momentum is not None:
             mom = bn.momentum
@@ -149,6 +150,9 @@ class DoubleConv(nn.Module):
         if head is not None:
             a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col, head.weight, head.bias)
+        elif pool:
+            a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col, None, None, True)
         else:
             a = ops.ConvBNReLU.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      tuple(c_valid), tuple(off), groups, training, mom, bn.eps, im2col)
@@ -160,22 +164,23 @@ class DoubleConv(nn.Module):
         return a
 
     def forward_nhwc(self, x0: Tensor, x1: Optional[Tensor] = None, c_valid=None, off=(0, 0), groups: int = 1,
-                     im2col: bool = False, head=None) -> Tensor:
+                     im2col: bool = False, head=None, pool: bool = False):
         conv0, bn0, conv1, bn1 = self.net[0], self.net[1], self.net[3], self.net[4]
         if c_valid is None:
             c_valid = (conv0.in_channels,)
         a = self._stage(conv0, bn0, x0, x1, c_valid, off, groups, im2col)
-        return self._stage(conv1, bn1, a, None, (conv0.out_channels,), (0, 0), groups, head=head)
+        return self._stage(conv1, bn1, a, None, (conv0.out_channels,), (0, 0), groups, head=head, pool=pool)
 
-    def first_layer_nhwc(self, x: Tensor, time_major: bool, groups: int) -> Tensor:
+    def first_layer_nhwc(self, x: Tensor, time_major: bool, groups: int, pool: bool = False):
         """f32 NCHW (or [B,T,C,H,W] with ``time_major``) input that needs no gradient -> pre-gathered first conv."""
         cin = self.net[0].in_channels
         if 9 * cin <= 64 and not x.requires_grad:
-            return self.forward_nhwc(ops.im2col_first(x.contiguous().float(), time_major), None, (cin,), (0, 0), groups, im2col=True)
+            return self.forward_nhwc(ops.im2col_first(x.contiguous().float(), time_major), None, (cin,), (0, 0), groups, im2col=True,
+                                     pool=pool)
         if time_major:
             B, T = x.shape[0], x.shape[1]
             x = x.transpose(0, 1).reshape(B * T, *x.shape[2:])
-        return self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()), None, (cin,), (0, 0), groups)
+        return self.forward_nhwc(ops.ToNHWC.apply(x.contiguous().float()), None, (cin,), (0, 0), groups, pool=pool)
 
     def forward(self, x):
         a = self.first_layer_nhwc(x, False, 1)
@@ -316,11 +321,19 @@ class TemporalUNetDualView(nn.Module):
 
     # -- internal NHWC encoder over n images in `groups` BatchNorm groups
     def _encode_nhwc(self, x: Tensor, time_major: bool, groups: int):
-        x0 = self.inc.first_layer_nhwc(x, time_major, groups)
-        x1, x0 = self.down1.forward_nhwc_skip(x0, groups)
-        x2, x1 = self.down2.forward_nhwc_skip(x1, groups)
-        x3, x2 = self.down3.forward_nhwc_skip(x2, groups)
-        xb, x3 = self.bottleneck.forward_nhwc_skip(x3, groups)
+        if ops.FUSE_POOL and ops.POOL_SKIP:
+            # every block's second BatchNorm stage also writes its pooled output (and takes both gradients back in one kernel)
+            x0, p0 = self.inc.first_layer_nhwc(x, time_major, groups, pool=True)
+            x1, p1 = self.down1.net[1].forward_nhwc(p0, groups=groups, pool=True)
+            x2, p2 = self.down2.net[1].forward_nhwc(p1, groups=groups, pool=True)
+            x3, p3 = self.down3.net[1].forward_nhwc(p2, groups=groups, pool=True)
+            xb = self.bottleneck.net[1].forward_nhwc(p3, groups=groups)
+        else:
+            x0 = self.inc.first_layer_nhwc(x, time_major, groups)
+            x1, x0 = self.down1.forward_nhwc_skip(x0, groups)
+            x2, x1 = self.down2.forward_nhwc_skip(x1, groups)
+            x3, x2 = self.down3.forward_nhwc_skip(x2, groups)
+            xb, x3 = self.bottleneck.forward_nhwc_skip(x3, groups)
         if self.use_attention:
             xb = self.attention.forward_nhwc(xb, self.base_ch * 16)
         return xb, (x3, x2, x1, x0)

@@ -1165,7 +1165,9 @@ class ConvBNReLU(_GradAwareFunction):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, gamma, beta, running_mean, running_var, c_valid, off, groups, training, momentum, eps,
-                im2col, head_w=None, head_b=None):
+                im2col, head_w=None, head_b=None, pool=False):
+        # pool: also return MaxPool2d(2) of the activation -- (a, p) -- with the pooling fused into the BatchNorm kernels both ways
+        # (uclstm_bn_apply_relu_pool / uclstm_bn_pool_bwd_*); every encoder block output feeds the next block's pooling and a skip.
         # head_w / head_b: the model's 1x1 output convolution (ONE output channel) fused into this stage (training mode only,
         # uclstm_bn_head_*): the stage then returns y f32 [n_img, 1, H, W] instead of its activation, which never exists.
         _dev(x0, ACT, "x0")
@@ -1187,6 +1189,7 @@ class ConvBNReLU(_GradAwareFunction):
         out = torch.empty((n_img, H, W, Cop), dtype=x0.dtype, device=dev)
         K = _k(x0)
         need_bw = _will_backward(ctx)
+        pooled = None
         if training:
             ppg = (n_img // groups) * H * W
             tpg = L.lib.uclstm_igemm_tiles_per_group(n_img, H, W, groups, Cop)
@@ -1215,6 +1218,12 @@ class ConvBNReLU(_GradAwareFunction):
                 _timed_hbm("bn_head_fwd", 2.0 * z.numel() + 4.0 * n_img * H * W,
                            lambda: L.check(K.uclstm_bn_head_fwd(_p(z), _p(par[0]), _p(par[1]), _p(head_w), _p(head_b), _p(a), n_img * H * W, ppg,
                                                                 Cop, Co, _stream()), "bn_head_fwd"))
+            elif pool and H % 2 == 0 and W % 2 == 0 and Cop // 8 <= 256:
+                a = torch.empty_like(z)
+                pooled = torch.empty((n_img, H // 2, W // 2, Cop), dtype=z.dtype, device=dev)
+                _timed_hbm("bn_apply_relu_pool", 4.5 * z.numel(),
+                           lambda: L.check(K.uclstm_bn_apply_relu_pool(_p(z), _p(a), _p(pooled), _p(par[0]), _p(par[1]), n_img, H, W, Cop,
+                                                                       groups, _stream()), "bn_apply_relu_pool"))
             else:
                 a = torch.empty_like(z)
                 _timed_hbm("bn_apply_relu", 4.0 * z.numel(),        # 2 B read + 2 B written per element
@@ -1248,10 +1257,19 @@ class ConvBNReLU(_GradAwareFunction):
                         col_scale=par[0], col_shift=par[1], relu=True)
             ctx.save_for_backward(x0, x1, weight, None, None, gamma, beta, bias, None, None)
         ctx.cfg = (tuple(c_valid), tuple(off), groups, training, im2col, Co, Ci_total, bias is not None)
+        ctx.pool = bool(pool)
+        if pool:
+            ctx.pool_fused = pooled is not None
+            if pooled is None:          # evaluation mode, odd sizes: the stand-alone pooling kernel on the finished activation
+                pooled = torch.empty((n_img, H // 2, W // 2, Cop), dtype=a.dtype, device=dev)
+                L.check(K.uclstm_maxpool2_fwd(_p(a), _p(pooled), n_img, H, W, Cop, _stream()), "maxpool2_fwd")
+                if need_bw:
+                    ctx.pool_act = a
+            return a, pooled
         return a
 
     @staticmethod
-    def backward(ctx, da):
+    def backward(ctx, da, dp=None):
         x0, x1, weight, z, par, gamma, beta, bias, head_w, head_b = ctx.saved_tensors
         c_valid, off, groups, training, im2col, Co, Ci_total, has_bias = ctx.cfg
         n_img, H, W, Cop = z.shape
@@ -1282,7 +1300,29 @@ class ConvBNReLU(_GradAwareFunction):
                     grad_written(head_b)
             else:
                 d_head_w, d_head_b = dwh, (dbh if head_b is not None else None)
+        elif ctx.pool and dp is not None and ctx.pool_fused:
+            # pooling fused: the gradient of the activation is (skip gradient) + scatter(dp), formed inside the BatchNorm kernels
+            dsk = None if da is None else da.contiguous()
+            dp = dp.contiguous()
+            prt = torch.empty((int(L.lib.uclstm_bn_pool_bwd_rows(n_img, H, W, Cop, groups)), Cop, 2), dtype=F32, device=dev)
+            _timed_hbm("bn_pool_bwd_reduce", (4.5 if dsk is not None else 2.5) * z.numel(),
+                       lambda: L.check(K.uclstm_bn_pool_bwd_reduce(_p(z), _p(dsk), _p(dp), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
+                                                                   _p(prt), _p(sums), n_img, H, W, Cop, groups, _stream()),
+                                       "bn_pool_bwd_reduce"))
+            sums_dz = sums if training else torch.zeros_like(sums)
+            _timed_hbm("bn_pool_bwd_apply", (6.5 if dsk is not None else 4.5) * z.numel(),
+                       lambda: L.check(K.uclstm_bn_pool_bwd_apply(_p(z), _p(dsk), _p(dp), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]),
+                                                                  _p(sums_dz), _p(dz), n_img, H, W, Cop, groups, _stream()),
+                                       "bn_pool_bwd_apply"))
         else:
+            if ctx.pool and dp is not None:
+                # pooling not fused (odd sizes / evaluation-mode statistics path): the stand-alone max-pool backward kernel first
+                act = ctx.pool_act
+                odd = bool(H % 2 or W % 2)
+                dfull = torch.zeros_like(act) if odd else torch.empty_like(act)
+                add = da.contiguous() if (da is not None and not odd) else None
+                L.check(K.uclstm_maxpool2_bwd(_p(act), _p(dp.contiguous()), _p(add), _p(dfull), n_img, H, W, Cop, _stream()), "maxpool2_bwd")
+                da = dfull if (da is None or add is not None) else dfull + da
             da = da.contiguous()
             _timed_hbm("bn_bwd_reduce", 4.0 * z.numel(),            # z and da read once
                        lambda: L.check(K.uclstm_bn_bwd_reduce(_p(z), _p(da), _p(par[0]), _p(par[1]), _p(par[2]), _p(par[3]), _p(partials),
@@ -1354,7 +1394,7 @@ class ConvBNReLU(_GradAwareFunction):
             wd = pack_weights(dd, weight, c_valid[0] * 9, dz.dtype)
             dx1 = torch.empty_like(x1)
             igemm_store([SrcView(dz)], wd, (H, W), n_img, [(dx1, 0, dd.N, 0, 1, -off[0], -off[1])], ktap=3, pad=1)
-        return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, d_head_w, d_head_b
+        return dx0, dx1, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, d_head_w, d_head_b, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1709,6 +1749,7 @@ class ConvLSTMSeq(torch.autograd.Function):
 # the other; they do not depend on each other)
 # ---------------------------------------------------------------------------------------------
 GROUP_LSTM = os.environ.get("UCLSTM_GROUP_LSTM", "1") != "0"
+FUSE_POOL = os.environ.get("UCLSTM_FUSE_POOL", "1") != "0"          # MaxPool2d(2) fused into the BatchNorm stage that feeds it (training)
 FUSE_HEAD = os.environ.get("UCLSTM_FUSE_HEAD", "1") != "0"          # 1x1 output convolution fused into the last BatchNorm stage (training)
 _GROUP_PLANS: dict = {}
 _CUS = 256
