@@ -1,6 +1,6 @@
 // Probe: what does a READ-ONLY stream reach on this chip, next to a copy of the same buffer?
 // The BatchNorm backward reductions (two reads, no write) run at 3.9 - 4.2 TB/s; this says whether that is the ceiling.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/_bin/bw_read tools/probes/bw_read.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/_bin/bw_read tools/probes/bw_read.hip ; run on the GPU box: bw_read [MiB].
 // Output: one line per (kernel, blocks per CU, loads in flight): GB/s over 20 launches after 3 warm-up launches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -75,8 +75,9 @@ static double time_ms(F launch) {
     return ms / 20.0;
 }
 
-int main() {
-    const size_t bytes = (size_t)1342177280;          // 1.34 GB: the largest activation of the headline step, far beyond L2 + MALL
+int main(int argc, char** argv) {
+    // default 1.34 GB: far beyond L2 + MALL.  `bw_read 320` = 335.5 MB, the largest activation of the headline step.
+    const size_t bytes = (argc > 1 ? (size_t)atol(argv[1]) : (size_t)1280) << 20;
     const size_t n16 = bytes / 16;
     uint4 *a, *b; unsigned* sink;
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&sink, 4));
