@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     # (frames x H x W, groups = timesteps, channels): the four encoder / decoder resolutions of the 64 x 64 seq-20 B=32 step
     shapes = [(640 * 64 * 64, 20, 64), (640 * 32 * 32, 20, 128), (640 * 16 * 16, 20, 256), (640 * 8 * 8, 20, 512)]
-    tag = os.environ.get("UCLSTM_BN_BWD_BLOCKS", "default(4096)")
+    tag = os.environ.get("UCLSTM_BN_BWD_BLOCKS", "default(1024)")
     for pixels, groups, Cp in shapes:
         ppg = pixels // groups
         z = torch.randn(pixels, Cp, device=dev).to(torch.bfloat16)

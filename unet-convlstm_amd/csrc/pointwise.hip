@@ -1533,7 +1533,10 @@ extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* sca
 
 namespace {
 inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
-    static const int total = [] { const char* e = getenv("UCLSTM_BN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+    // 1024 blocks in total (four per CU): isolated, the reduction takes 142 us instead of 156 at 4096 on the 64-channel full-resolution
+    // stage and 77 instead of 86 on the 128-channel one (profiles/round3_bn_reduce_blocks.txt); read streams on this chip are fastest
+    // with FEW blocks per CU (tools/probes/bw_read.hip)
+    static const int total = [] { const char* e = getenv("UCLSTM_BN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
     const int cap = (total + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
