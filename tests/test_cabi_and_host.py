@@ -532,3 +532,21 @@ def test_pack_job_table_families_and_segments():
     assert ops.pack_segments(sizes, ()) == [0] * 6
     seg = ops.pack_segments([7] * 40, ops.PACK_SEGMENTS)
     assert seg[0] == 0 and seg == sorted(seg) and seg[-1] == len(ops.PACK_SEGMENTS)
+
+
+def test_store_split_k_long_k_rule_is_off_by_default_and_narrow_when_on(monkeypatch):
+    """ops.store_split_k: K ranges of a statistics-free store convolution.  The long-K rule is OFF by default: alone it makes one launch
+    of the headline step 23 % faster, in the overlapped step the backward phase does not gain (profiles/round3_store_splitk*.txt).
+    Switched on (288 K-steps) it must pick 2 ranges only for the two measured winners and leave every shape that LOST alone."""
+    assert ops.SPLITK_STORE_LONGK_STEPS == 0 or "UCLSTM_SPLITK_STORE_LONGK" in os.environ
+    monkeypatch.setattr(ops, "SPLITK_STORE_LONGK_STEPS", 0)
+    assert ops.store_split_k(640 * 16, 1024, 36864 // 64) == 1
+    monkeypatch.setattr(ops, "SPLITK_STORE_LONGK_STEPS", 288)
+    assert ops.store_split_k(640 * 16, 1024, 36864 // 64) == 2                       # temporal ConvLSTM input gradient, 64 x 64 seq-20 B=32
+    assert ops.store_split_k(48 * 256, 1024, 36864 // 64) == 2                        # the same layer at 256 x 256 seq-12 B=4: 384 tiles, measured
+    lost = [(640 * 64, 512, 4608), (640 * 16, 1024, 9216), (640 * 64, 512, 18432), (640 * 16, 1024, 4608), (640 * 16, 512, 9216),
+            (640 * 64, 256, 4608), (640 * 64, 512, 2304), (640 * 256, 256, 2304)]
+    for pixels, N, K in lost:
+        assert ops.store_split_k(pixels, N, K // 64) == 1, (pixels, N, K)
+    assert ops.store_split_k(256 * 64, 1024, 36864 // 64) == 1                        # 128 x 128 seq-8 B=32: 512 tiles = two exact rounds
+    assert ops.store_split_k(1 * 16 * 16, 256, 2304 // 64) > 1                         # the old small-grid rule (batch-1 inference) still applies

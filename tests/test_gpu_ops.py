@@ -835,7 +835,10 @@ def test_convlstm_5x5_and_7x7_gate_convolutions_golden(k):
         U.ConvLSTMCell(4, 8, kernel_size=4)
 
 
-@pytest.mark.parametrize("N,Ci,Co,H,W,dtype", [(1, 256, 256, 16, 16, "bf16"), (1, 512, 136, 8, 8, "bf16"), (2, 128, 128, 8, 12, "f16")])
+# last case: the long-K rule of ops.store_split_k (65 x 4 = 260 tiles of 128 x 256, 288 K-steps), the shape class of the temporal
+# ConvLSTM's input gradient in the headline step
+@pytest.mark.parametrize("N,Ci,Co,H,W,dtype", [(1, 256, 256, 16, 16, "bf16"), (1, 512, 136, 8, 8, "bf16"), (2, 128, 128, 8, 12, "f16"),
+                                               (520, 2048, 1024, 4, 4, "bf16")])
 def test_split_k_store_convolution_equals_the_single_pass(N, Ci, Co, H, W, dtype):
     """Inference convolutions on few pixels run as K ranges + uclstm_splitk_finish (bias, folded BatchNorm, ReLU): against the
     one-pass kernel the f32 sums differ only in their association, so after rounding to 16 bits almost every element is
@@ -855,7 +858,9 @@ def test_split_k_store_convolution_equals_the_single_pass(N, Ci, Co, H, W, dtype
     bp, scp, shp = pad(b), pad(sc), pad(sh)
     outs = {}
     ops.KERNEL_LOG = []
+    longk = ops.SPLITK_STORE_LONGK_STEPS
     try:
+        ops.SPLITK_STORE_LONGK_STEPS = 288          # the long-K rule is off by default (see ops.py); the last case exercises it
         for split in (True, False):
             ops.SPLITK_STORE = split
             out = torch.full((N, H, W, Cop), 7.0, dtype=dt, device=DEV)
@@ -865,12 +870,20 @@ def test_split_k_store_convolution_equals_the_single_pass(N, Ci, Co, H, W, dtype
         epis = [e for e, _ in ops.KERNEL_LOG]
     finally:
         ops.SPLITK_STORE = True
+        ops.SPLITK_STORE_LONGK_STEPS = longk
         ops.KERNEL_LOG = None
     assert epis == [U._lib.EPI_ATOMIC, U._lib.EPI_STORE], epis            # the first call really took the split-K path
     a, c = outs[True].float(), outs[False].float()
     ulp = 2.0 ** (-7 if dtype == "bf16" else -10)
     diff = (a - c).abs()
-    assert bool((diff <= ulp * c.abs().clamp_min(2.0 ** -10) * 1.01).all()), float(diff.max())
+    # ... plus two f32 units of the ACCUMULATED magnitude (sum of |products|, scaled): with 18432-term sums of magnitude ~7 a handful
+    # of outputs cancel to ~1e-3, where the f32 association difference of the two paths (1e-5, below one f32 rounding of the sum) is
+    # 1 - 2 units of the tiny result (tools/debug_splitk_longk.py: 6 of 8.5 M elements, both paths 1.662e-3 from f64).  Negligible
+    # for the short-K cases.
+    mag = torch.zeros(N, H, W, Cop)
+    mag[..., :Co] = (F.conv2d(x.abs(), w.abs(), None, padding=1) * sc.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    bound = ulp * c.abs().clamp_min(2.0 ** -10) * 1.01 + 2.0 ** -23 * mag.to(DEV)
+    assert bool((diff <= bound).all()), (float(diff.max()), int((diff > bound).sum()))
     frac = float((diff > 0).float().mean())
     print(f"[parity] split-K store vs one pass ({dtype}): {frac:.4%} of elements differ (by one unit in the last place)")
     assert frac <= 0.02

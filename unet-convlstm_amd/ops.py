@@ -767,6 +767,26 @@ def _same_act_dtype(tensors, what: str) -> None:
 # evaluation-mode statistics): below SPLITK_STORE_BELOW 128 x 128 tiles.  UCLSTM_SPLITK_STORE=0 switches it off.
 SPLITK_STORE = os.environ.get("UCLSTM_SPLITK_STORE", "1") != "0"
 SPLITK_STORE_BELOW = int(os.environ.get("UCLSTM_SPLITK_STORE_BELOW", "192"))
+# Second rule, OFF by default (UCLSTM_SPLITK_STORE_LONGK=288 switches it on): a grid of 128 x 256 tiles that needs a second round of the
+# 256 CUs for at most half a round's worth of tiles, on a LONG K, as two K ranges.  Measured (tools/bench_store_splitk.py,
+# profiles/round3_store_splitk.txt, finish pass included): alone, 320 tiles x K = 36864 (the temporal ConvLSTM's input gradient over all
+# timesteps) 823 -> 632 us and 384 tiles (the same layer at 256 x 256, B = 4) 792 -> 741 us; 320 tiles x K = 9216 +-3 %; every other
+# under-filled shape (160 / 320 / 640 tiles, K <= 18432) LOSES 2 - 70 %.  In the STEP, where the weight-gradient stream runs beside
+# the main stream, the rule fires (igemm_fwd_store_splitk, 0.786 -> 0.611 ms serialised) and the backward phase gets no shorter:
+# 20.643 -> 20.678 ms, slower in three of three same-box pairs (profiles/round3_store_splitk_step_ab.txt) -- the CUs the under-filled
+# round leaves idle are taken by the other stream, and the slabs + finish pass are extra work.  Useful only for serialised /
+# single-stream execution, hence a switch and not the default.
+SPLITK_STORE_LONGK_STEPS = int(os.environ.get("UCLSTM_SPLITK_STORE_LONGK", "0"))          # K-steps of 64 from which it applies; 0 = off
+
+
+def store_split_k(pixels: int, N: int, ksteps: int) -> int:
+    """K ranges of a store-epilogue convolution without BatchNorm statistics (1 = one pass).  Pure function of the shape."""
+    ks = split_k_factor(pixels, N, ksteps, min_blocks=SPLITK_STORE_BELOW)
+    if ks == 1 and SPLITK_STORE_LONGK_STEPS > 0 and ksteps >= SPLITK_STORE_LONGK_STEPS:
+        tiles = ((pixels + 127) // 128) * ((N + 255) // 256)
+        if 256 < tiles <= 384:
+            ks = 2
+    return ks
 
 
 def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, int], n_img: int, segs, *, ktap: int, scale: int = 1,
@@ -792,7 +812,7 @@ def igemm_store(srcs: Sequence[SrcView], wp: torch.Tensor, out_hw: Tuple[int, in
         t, n_begin, n_end, c_off, sg_scale, oy, ox = (tuple(segs[0]) + (0, 1, 0, 0))[:7]
         N, pixels = wp.shape[0], n_img * out_hw[0] * out_hw[1]
         if (n_begin, n_end, c_off, sg_scale, oy, ox) == (0, N, 0, 1, 0, 0) and t.is_contiguous() and tuple(t.shape) == (n_img, out_hw[0], out_hw[1], N):
-            ksplit = split_k_factor(pixels, N, wp.shape[1] // 64, min_blocks=SPLITK_STORE_BELOW)
+            ksplit = store_split_k(pixels, N, wp.shape[1] // 64)
             if ksplit > 1:
                 nsl = ksplit_used(wp.shape[1], ksplit, ktap)
                 pre = torch.empty((nsl, pixels, N), dtype=F32, device=t.device)
