@@ -1533,9 +1533,11 @@ extern "C" int32_t uclstm_bn_apply_relu(const void* z, void* a, const float* sca
 
 namespace {
 inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
-    // 1024 blocks in total (four per CU): isolated, the reduction takes 142 us instead of 156 at 4096 on the 64-channel full-resolution
-    // stage and 77 instead of 86 on the 128-channel one (profiles/round3_bn_reduce_blocks.txt); read streams on this chip are fastest
-    // with FEW blocks per CU (tools/probes/bw_read.hip)
+    // 1024 blocks in total (four per CU).  Alone, on cold tensors, the reduction takes 142 us instead of 156 at 4096 on the 64-channel
+    // full-resolution stage and 77 instead of 86 on the 128-channel one (profiles/round3_bn_reduce_blocks.txt).  Inside the step the
+    // reduction kernel itself is 6 % slower than with 4096 (its inputs were just written) and the gain is in bn_bwd_sum_kernel, which
+    // adds a quarter of the rows (8.2 -> 5.5 us), and in the head variant (profiles/round3_bn_reduce_blocks_instep.txt); backward phase
+    // -0.08 ms in three of three same-box pairs
     static const int total = [] { const char* e = getenv("UCLSTM_BN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
     const int cap = (total + groups - 1) / groups;
