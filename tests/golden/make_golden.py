@@ -447,6 +447,8 @@ def gen_cell_k():
 SEEDED = {
     # BASELINE configs[1] at the benchmark's own batch (the kernel plan the driver times): base_ch 64 + skip LSTMs, B=32
     "ref_cfg1_b32": dict(base_ch=64, skip=True, B=32, T=2, HW=64, kind="uniform", seed=900, use_mask=False),
+    # SURVEY 8(d) cfg 2 names "P and S": the reference's class defaults (train/unet.py:132: base_ch 32, no skip LSTMs) at the same batch
+    "ref_cfgS_b32": dict(base_ch=32, skip=False, B=32, T=2, HW=64, kind="uniform", seed=905, use_mask=False),
     # well-sized autocast anchor (BatchNorm statistics over >= 256 values per channel at every level)
     "ref_autocast_b16": dict(base_ch=8, skip=True, B=16, T=3, HW=64, kind="uniform", seed=910, use_mask=True, with_fp16=True),
     # Moving-MNIST-shaped blobs through the full model

@@ -139,6 +139,13 @@ def test_config1_train_forward_also_matches_bf16_storage_oracle():
     assert max(e) <= 1.5e-2
 
 
+def test_secondary_model_S_at_the_benchmark_batch_vs_reference():
+    """SURVEY 8(d) cfg 2 names P *and* S: the reference's class defaults (train/unet.py:132: base_ch 32, use_skip_lstm False) at
+    B=32, 64x64 -- eval and train forward, loss, whole and per-tensor gradients against the reference's own f32 run and its own
+    autocast drift.  One ConvLSTM only (hidden 512 on 4x4 pixels, M = 512 per timestep: split-K partial tiles)."""
+    check_case("ref_cfgS_b32")
+
+
 def test_autocast_anchor_case_b16():
     check_case("ref_autocast_b16")
 

@@ -190,7 +190,7 @@ import pytest
 from conftest import seeded_case, load_golden_np, checksum, rel_l2, mr_rel_l2_per_t
 
 
-@pytest.mark.parametrize("name", ["ref_autocast_b16", "ref_blobs64", "ref_cloud128", "ref_256", "ref_cfg1_b32"])
+@pytest.mark.parametrize("name", ["ref_autocast_b16", "ref_blobs64", "ref_cloud128", "ref_256", "ref_cfg1_b32", "ref_cfgS_b32"])
 def test_oracle_matches_reference_at_baseline_shapes(name):
     """Eval forward, train forward, loss and every per-tensor gradient norm of the oracle against the reference's own f32
     run -- at the benchmark width (base_ch 64, B=32), on Moving-MNIST-shaped blobs, at 128x128 and 256x256."""
