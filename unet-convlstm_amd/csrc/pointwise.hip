@@ -227,8 +227,12 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
     extern __shared__ float red[];     // [rows][cpc*16]
     const int g = blockIdx.x / blocks_per_group;
     const int bi = blockIdx.x - g * blocks_per_group;
-    const int64_t p0 = (int64_t)g * ppg + (int64_t)bi * pix_per_block;
-    const int64_t p1 = min((int64_t)(g + 1) * ppg, p0 + pix_per_block);
+    // A block takes every blocks_per_group-th SWEEP (4*rows consecutive pixels) of its group, not a contiguous pixel range: the
+    // blocks of a group then read next to each other at every moment (one moving front per tensor, as a grid-stride loop has)
+    // instead of from blocks_per_group distant places.  The block -> pixel mapping is fixed, so the sums stay reproducible.
+    const int64_t gbeg = (int64_t)g * ppg, gend = gbeg + ppg;
+    const int64_t sweep = 4 * (int64_t)cg.rows;
+    (void)pix_per_block;
     // thread t handles chunk column t % cpc of rows t / cpc + k*rows; columns beyond 256 threads loop
     for (int cbase = 0; cbase < cg.cpc; cbase += NT) {
         const int cc = cbase + (cg.cpc >= NT ? threadIdx.x : threadIdx.x % cg.cpc);
@@ -237,13 +241,15 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
         float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const long so = (long)g * Cp + cc * 8;
-            float sc[8], sh[8], mu[8], rs[8];
+            float sc[8], sh[8], mu[8];
             load8f(scale + so, sc);
             load8f(shift + so, sh);
             load8f(mean + so, mu);
-            load8f(rstd + so, rs);
-            int64_t p = p0 + prow;
-            for (; p + 3 * cg.rows < p1; p += 4 * cg.rows) {       // four pixel rows (eight 16-byte loads) in flight
+            // s2 = rstd * sum g_*(z - mean): rstd is a per-channel constant, applied once after the loop (one fused multiply-add per
+            // element instead of subtract, two multiplies and an add; eight registers fewer inside the loop)
+            int64_t p = gbeg + (int64_t)bi * sweep + prow;
+            const int64_t step = sweep * blocks_per_group;
+            for (; p + 3 * cg.rows < gend; p += step) {             // four pixel rows (eight 16-byte loads) in flight
                 uint4 zq[4], gq[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -259,21 +265,26 @@ __global__ void bn_bwd_reduce_kernel(const uint4* __restrict__ z, const uint4* _
                     for (int i = 0; i < 8; ++i) {
                         const float g0 = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
                         s1[i] += g0;
-                        s2[i] += g0 * (zv[i] - mu[i]) * rs[i];
+                        s2[i] = fmaf(g0, zv[i] - mu[i], s2[i]);
                     }
                 }
             }
-            for (; p < p1; p += cg.rows) {
+            // the group's last, partial sweep (at most one per thread: p advanced past every full one)
+            for (int u = 0; u < 4 && p + u * cg.rows < gend; ++u) {
                 float zv[8], gv[8];
-                unpack8(z[p * cg.cpc + cc], zv);
-                unpack8(da[p * cg.cpc + cc], gv);
+                unpack8(z[(p + u * cg.rows) * cg.cpc + cc], zv);
+                unpack8(da[(p + u * cg.rows) * cg.cpc + cc], gv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float gg = (zv[i] * sc[i] + sh[i] > 0.f) ? gv[i] : 0.f;
                     s1[i] += gg;
-                    s2[i] += gg * (zv[i] - mu[i]) * rs[i];
+                    s2[i] = fmaf(gg, zv[i] - mu[i], s2[i]);
                 }
             }
+            float rs[8];
+            load8f(rstd + so, rs);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s2[i] *= rs[i];
         }
         const int width = min(cg.cpc, NT) * 16;
         if (act) {
@@ -1539,8 +1550,13 @@ inline int bn_bwd_blocks_per_group(int64_t pixels_per_group, int groups) {
     // adds a quarter of the rows (8.2 -> 5.5 us), and in the head variant (profiles/round3_bn_reduce_blocks_instep.txt); backward phase
     // -0.08 ms in three of three same-box pairs
     static const int total = [] { const char* e = getenv("UCLSTM_BN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
-    const int cap = (total + groups - 1) / groups;
+    // at least 32 pixel rows per block (128 until round 3: the 8x8 and 4x4 stages of the headline step then ran on 320 and 80 blocks;
+    // in the serialised step bn_bwd_apply_cols 68.2 -> 63.6 us on average, the reduction no slower; profiles/round3_bn_instep_ab.txt)
+    static const int min_rows = [] { const char* e = getenv("UCLSTM_BN_BWD_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
+    int bpg = (int)((pixels_per_group + min_rows - 1) / min_rows);
+    // rounded DOWN: the reductions hold four blocks per CU (122 VGPRs), i.e. 1024 at once; with 20 groups a cap of ceil(1024 / 20) = 52
+    // made 1040 blocks, and the last 16 ran as a second round on an empty chip (~10 us of tail on a 150-us launch)
+    const int cap = total / groups;
     if (bpg > cap) bpg = cap;
     return bpg < 1 ? 1 : bpg;
 }
@@ -1582,7 +1598,10 @@ extern "C" int32_t uclstm_bn_bwd_apply(const void* z, const void* da, const floa
     const ColGeom cg = col_geom(Cp);
     if (cg.cpc <= NT && (pixels % pixels_per_group) == 0) {
         const int groups = (int)(pixels / pixels_per_group);
-        int bpg = (int)((pixels_per_group + 127) / 128);          // >= 128 pixel rows per block
+        // at least 32 pixel rows per block (128 until round 3: the 8x8 and 4x4 stages of the headline step then ran on 320 and 80 blocks;
+    // in the serialised step bn_bwd_apply_cols 68.2 -> 63.6 us on average, the reduction no slower; profiles/round3_bn_instep_ab.txt)
+    static const int min_rows = [] { const char* e = getenv("UCLSTM_BN_BWD_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
+    int bpg = (int)((pixels_per_group + min_rows - 1) / min_rows);
         const int cap = (4096 + groups - 1) / groups;
         if (bpg > cap) bpg = cap;
         if (bpg < 1) bpg = 1;
@@ -1608,7 +1627,9 @@ static bool pool_plan(int64_t n_img, int H, int W, int Cp, int groups, ColGeom& 
     pg.dHoWo = make_fastdiv((uint32_t)(pg.Ho * pg.Wo));
     pg.wpg = (n_img / groups) * (int64_t)pg.Ho * pg.Wo;
     bpg = (int)((pg.wpg + 31) / 32);                     // >= 32 windows (128 pixels) per thread row
-    const int cap = (4096 + groups - 1) / groups;
+    // total block count rounded DOWN per group (see bn_bwd_blocks_per_group); UCLSTM_BN_POOL_BLOCKS for A/B runs
+    static const int total = [] { const char* e = getenv("UCLSTM_BN_POOL_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+    const int cap = total / groups;
     if (bpg > cap) bpg = cap;
     if (bpg < 1) bpg = 1;
     wpb = (pg.wpg + bpg - 1) / bpg;
