@@ -592,11 +592,10 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const uint4* __r
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const long so = (long)g * Cp + cc * 8;
-        float sc[8], sh[8], mu[8], rs[8];
+        float sc[8], sh[8], mu[8];
         load8f(scale + so, sc);
         load8f(shift + so, sh);
         load8f(mean + so, mu);
-        load8f(rstd + so, rs);
         const int64_t offs[4] = {0, cg.cpc, (int64_t)pg.W * cg.cpc, (int64_t)pg.W * cg.cpc + cg.cpc};
         for (int64_t wi = w0 + prow; wi < w1; wi += cg.rows) {
             const int64_t b0 = pool_base(pg, wi, cg.cpc, cc);
@@ -615,9 +614,13 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const uint4* __r
                 for (int i = 0; i < 8; ++i) {
                     const float g0 = (zv[k][i] * sc[i] + sh[i] > 0.f) ? da[k][i] : 0.f;
                     s1[i] += g0;
-                    s2[i] += g0 * (zv[k][i] - mu[i]) * rs[i];
+                    s2[i] = fmaf(g0, zv[k][i] - mu[i], s2[i]);
                 }
         }
+        float rs[8];                                   // rstd once per channel after the loop, as in bn_bwd_reduce_kernel
+        load8f(rstd + so, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s2[i] *= rs[i];
     }
     const int width = cg.cpc * 16;
     if (act) {
@@ -750,6 +753,8 @@ __global__ void bn_head_bwd_reduce_kernel(const uint4* __restrict__ z, const flo
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
     if (act) {
         const long so = (long)g * Cp + cc * 8;
+        // (rstd stays inside the loop here: hoisted as in bn_bwd_reduce_kernel the allocator spills 36 B instead of 12 at the 128-VGPR
+        // cap and the kernel is 7 % slower in the step, 90 -> 96 us; profiles/round3_bn_instep_ab.txt)
         float sc[8], sh[8], mu[8], rs[8], wr[8];
         load8f(scale + so, sc);
         load8f(shift + so, sh);
