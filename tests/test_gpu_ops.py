@@ -295,6 +295,70 @@ def test_colsum(pixels, Cp):
     torch.testing.assert_close(got, a.float().sum(0), rtol=1e-4, atol=2e-3 * pixels ** 0.5)
 
 
+# (pixels per group, groups, padded channels): ragged groups that end inside a sweep of 4 x rows pixels, a group smaller than one sweep,
+# 128 chunks per pixel (two pixel rows per block sweep), the column loop (more than 256 chunks per pixel, with and without a remainder),
+# more groups than the block budget (one block per group), a chunk count that does not divide 256, and a many-block case
+BN_BWD_SHAPES = [(131, 3, 64), (5000, 2, 64), (777, 2, 1024), (300, 1, 4096), (50, 3, 2056), (7, 1100, 8), (33, 5, 24), (40960, 2, 64)]
+
+
+@pytest.mark.parametrize("ppg,groups,Cp", BN_BWD_SHAPES)
+def test_bn_bwd_reduce_and_apply_against_f64_at_the_c_abi(ppg, groups, Cp):
+    """uclstm_bn_bwd_reduce / uclstm_bn_bwd_apply directly, against the same formulas in f64 on the same 16-bit inputs (DESIGN 3:
+    s1 = sum g_, s2 = sum g_*xhat over the pixels of a group with g_ = da where relu(z*scale+shift) > 0; dz = scale*(g_ - s1/n -
+    xhat*s2/n)).  TIGHT on purpose: the conv+BN+ReLU operator tests compare with an f32 oracle at 1e-2, which would not see a block
+    -> pixel mapping that drops or repeats the last rows of a group (an error of rows / pixels).  Elements whose pre-activation is
+    within 1e-4 of zero get a zero gradient, so that the f32 / f64 sign of the ReLU mask cannot differ."""
+    torch.manual_seed(1000 + ppg + Cp)
+    pixels = ppg * groups
+    z = bf(torch.randn(pixels, Cp))
+    da = bf(torch.randn(pixels, Cp))
+    scale, shift = torch.rand(groups, Cp) + 0.5, torch.randn(groups, Cp) * 0.5
+    scale[:, ::3] *= -1.0                                           # negative gamma: the mask is on z*scale+shift, not on z
+    mean, rstd = torch.randn(groups, Cp) * 0.3, torch.rand(groups, Cp) + 0.5
+    gi = torch.arange(pixels) // ppg
+    y64 = z.double() * scale.double()[gi] + shift.double()[gi]
+    da = torch.where(y64.abs() < 1e-4, torch.zeros_like(da), da)
+    g0 = torch.where(y64 > 0, da.double(), torch.zeros_like(y64))
+    xhat = (z.double() - mean.double()[gi]) * rstd.double()[gi]
+    s1 = g0.view(groups, ppg, Cp).sum(1)
+    s2 = (g0 * xhat).view(groups, ppg, Cp).sum(1)
+    a1 = g0.abs().view(groups, ppg, Cp).sum(1)                      # accumulated magnitudes: the scale of f32 summation error
+    a2 = (g0 * xhat).abs().view(groups, ppg, Cp).sum(1)
+
+    zd, dad = z.to(DEV).to(torch.bfloat16).contiguous(), da.to(DEV).to(torch.bfloat16).contiguous()
+    par = [t.to(DEV).contiguous() for t in (scale, shift, mean, rstd)]
+    rows = int(U._lib.lib.uclstm_bn_bwd_reduce_rows(pixels, ppg))
+    assert rows >= groups and rows % groups == 0
+    partials = torch.full((rows, Cp, 2), float("nan"), device=DEV)
+    sums = torch.full((groups, Cp, 2), float("nan"), device=DEV)
+    K = U._lib.kernels(torch.bfloat16)
+    U._lib.check(K.uclstm_bn_bwd_reduce(ops._p(zd), ops._p(dad), *[ops._p(t) for t in par], ops._p(partials), ops._p(sums), pixels, ppg, Cp,
+                                        ops._stream()), "bn_bwd_reduce")
+    got = sums.cpu().double()
+    assert torch.isfinite(got).all()
+    e1 = ((got[..., 0] - s1).abs() / (a1 + 1e-3)).max().item()
+    e2 = ((got[..., 1] - s2).abs() / (a2 + 1e-3)).max().item()
+    print(f"[parity] bn_bwd_reduce ppg={ppg} groups={groups} Cp={Cp} ({rows // groups} blocks per group): max |err| / sum|terms| s1 {e1:.2e} s2 {e2:.2e}")
+    assert e1 <= 2e-6 and e2 <= 2e-6, (e1, e2)
+
+    dz = torch.full((pixels, Cp), float("nan"), device=DEV, dtype=torch.bfloat16)
+    U._lib.check(K.uclstm_bn_bwd_apply(ops._p(zd), ops._p(dad), *[ops._p(t) for t in par], ops._p(sums), ops._p(dz), pixels, ppg, Cp,
+                                       ops._stream()), "bn_bwd_apply")
+    # the apply kernel alone: the reference takes the sums the kernel was given (its own f32 results), not the f64 ones
+    k1s, k2s = got[..., 0][gi], got[..., 1][gi]
+    ref = scale.double()[gi] * (g0 - k1s / ppg - xhat * k2s / ppg)
+    d = (dz.cpu().double() - ref).abs()
+    assert torch.isfinite(dz.float()).all()
+    # half a unit of bf16 at the value, plus f32 rounding of the terms before they cancel; the kernel evaluates the regrouped form
+    # scale*g_ + k1*z + k0 (k1 = -scale*rstd*s2/n, k0 = -scale*s1/n - k1*mean), whose terms scale with |z| + |mean|, not |z - mean|
+    k1 = (scale.double() * rstd.double())[gi].abs() * k2s.abs() / ppg
+    mag = scale.double()[gi].abs() * (g0.abs() + k1s.abs() / ppg) + k1 * (z.double().abs() + mean.double()[gi].abs())
+    bound = 2.0 ** -8 * ref.abs() * 1.01 + 2.0 ** -21 * mag + 1e-30
+    bad = int((d > bound).sum())
+    print(f"[parity] bn_bwd_apply  ppg={ppg} groups={groups} Cp={Cp}: {bad} of {d.numel()} elements beyond half a bf16 unit + f32 rounding; max diff {float(d.max()):.3e}")
+    assert bad == 0
+
+
 # ---------------------------------------------------------------------------------------------
 # weight gradient (ds_read_b64_tr_b16 path)
 # ---------------------------------------------------------------------------------------------
